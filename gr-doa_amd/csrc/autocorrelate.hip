@@ -1,0 +1,400 @@
+// autocorrelate.hip — K1: sliding-window sample covariance of N complex streams on gfx950.
+//
+// Replaces gr::doa::autocorrelate (reference lib/autocorrelate_impl.cc:47-118):
+//   R_i[a,b] = (1/K) * sum_{t<K} x_a[i*S + t] * conj(x_b[i*S + t]),   S = K - overlap,
+//   optional forward-backward step R <- 0.5 R + (0.5/K) J conj(R) J   (:107-108, the second
+//   term is divided by K a second time in the reference; reproduced).
+// Output items are column-major N x N complex64 (:103).
+//
+// Kernel shape (HBM-bound, ~1 flop/B): one 64-lane wave owns one snapshot.  Each lane streams
+// 16-byte (two-sample) loads from every channel — a wave instruction covers 1 KiB contiguous per
+// channel — and keeps the Hermitian upper triangle (N real + N(N-1)/2 complex partial sums) in
+// registers; partials meet in one wave all-reduce and lanes 0..N^2-1 write the 8N^2-byte item
+// as one contiguous segment.  No LDS, no atomics; with overlapping windows the re-read halo is
+// served by L2.  N > 8 runs as 8x8 channel tiles of the same loop.
+#include "common.hpp"
+
+namespace doa {
+
+struct CovArgs {
+    const float2 *in[DOA_MAX_ANT_ELE];
+    float2 *out;
+    int n_ch;      // N
+    int K;         // snapshot_size
+    int S;         // snapshot_size - overlap_size
+    int n_out;     // windows to produce
+    int avg;       // 1 = forward-backward
+    float inv_k;   // (float)(1.0/K)
+    float fb_hk;   // (float)(0.5/K)
+    int a0, b0;    // tile origin (tile kernel only)
+};
+
+template <int TN> struct TriAcc {
+    float d[TN];
+    float re[TN * (TN - 1) / 2 > 0 ? TN * (TN - 1) / 2 : 1];
+    float im[TN * (TN - 1) / 2 > 0 ? TN * (TN - 1) / 2 : 1];
+};
+
+template <int TN> __device__ __forceinline__ void tri_accumulate(TriAcc<TN> &acc, const float2 (&x)[TN])
+{
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+        acc.d[a] = fmaf(x[a].x, x[a].x, fmaf(x[a].y, x[a].y, acc.d[a]));
+#pragma unroll
+        for (int b = a + 1; b < TN; b++) {
+            // x_a * conj(x_b)
+            acc.re[idx] = fmaf(x[a].x, x[b].x, fmaf(x[a].y, x[b].y, acc.re[idx]));
+            acc.im[idx] = fmaf(x[a].y, x[b].x, fmaf(-x[a].x, x[b].y, acc.im[idx]));
+            idx++;
+        }
+    }
+}
+
+// One wave per snapshot, N = TN <= 8, Hermitian symmetry exploited.
+// VEC2: all streams 16-B aligned at every window start (base % 16 == 0, S even) -> float4 loads.
+template <int TN, bool VEC2>
+__global__ __launch_bounds__(256) void cov_wave_kernel(CovArgs g)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int snap = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (snap >= g.n_out) return;  // whole wave exits together
+    const size_t base = (size_t)snap * (size_t)g.S;
+
+    TriAcc<TN> acc;
+#pragma unroll
+    for (int a = 0; a < TN; a++) acc.d[a] = 0.f;
+#pragma unroll
+    for (int i = 0; i < TN * (TN - 1) / 2; i++) { acc.re[i] = 0.f; acc.im[i] = 0.f; }
+
+    if constexpr (VEC2) {
+        const int npair = g.K >> 1;
+#pragma unroll 4
+        for (int p = lane; p < npair; p += kWave) {
+            float4 v[TN];
+#pragma unroll
+            for (int a = 0; a < TN; a++) v[a] = *reinterpret_cast<const float4 *>(g.in[a] + base + 2 * (size_t)p);
+            float2 x0[TN], x1[TN];
+#pragma unroll
+            for (int a = 0; a < TN; a++) { x0[a] = make_float2(v[a].x, v[a].y); x1[a] = make_float2(v[a].z, v[a].w); }
+            tri_accumulate<TN>(acc, x0);
+            tri_accumulate<TN>(acc, x1);
+        }
+        if ((g.K & 1) && lane == 0) {
+            float2 x[TN];
+#pragma unroll
+            for (int a = 0; a < TN; a++) x[a] = g.in[a][base + (size_t)(g.K - 1)];
+            tri_accumulate<TN>(acc, x);
+        }
+    } else {
+#pragma unroll 4
+        for (int t = lane; t < g.K; t += kWave) {
+            float2 x[TN];
+#pragma unroll
+            for (int a = 0; a < TN; a++) x[a] = g.in[a][base + (size_t)t];
+            tri_accumulate<TN>(acc, x);
+        }
+    }
+
+    // wave all-reduce of the N^2 real partial sums
+#pragma unroll
+    for (int a = 0; a < TN; a++) acc.d[a] = wave_allreduce_sum(acc.d[a]);
+#pragma unroll
+    for (int i = 0; i < TN * (TN - 1) / 2; i++) {
+        acc.re[i] = wave_allreduce_sum(acc.re[i]);
+        acc.im[i] = wave_allreduce_sum(acc.im[i]);
+    }
+
+    // lane e = a + b*N picks element R[a,b]
+    float2 r = make_float2(0.f, 0.f);
+    {
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < TN; a++) {
+            if (lane == a + a * TN) r = make_float2(acc.d[a], 0.f);
+#pragma unroll
+            for (int b = a + 1; b < TN; b++) {
+                if (lane == a + b * TN) r = make_float2(acc.re[idx], acc.im[idx]);
+                if (lane == b + a * TN) r = make_float2(acc.re[idx], -acc.im[idx]);
+                idx++;
+            }
+        }
+    }
+    r.x = __fmul_rn(r.x, g.inv_k);
+    r.y = __fmul_rn(r.y, g.inv_k);
+    if (g.avg == 1) {
+        // (J conj(R) J)[a,b] = conj(R[N-1-a, N-1-b])  ->  element index N^2-1-e
+        const int src = (lane < TN * TN) ? (TN * TN - 1 - lane) : lane;
+        const float px = __shfl(r.x, src, kWave);
+        const float py = __shfl(r.y, src, kWave);
+        r.x = __fadd_rn(__fmul_rn(0.5f, r.x), __fmul_rn(g.fb_hk, px));
+        r.y = __fadd_rn(__fmul_rn(0.5f, r.y), __fmul_rn(g.fb_hk, -py));
+    }
+    if (lane < TN * TN) g.out[(size_t)snap * (TN * TN) + lane] = r;
+}
+
+// 8x8 channel tile of a wider array (8 < N <= 16): rows a0.., columns b0.. ; channels past N
+// alias channel 0 on the load side and are masked on the store side.  Off-diagonal tiles also
+// write the mirrored conjugate block.  FB averaging is applied afterwards by cov_fb_kernel.
+template <bool VEC2> __global__ __launch_bounds__(256) void cov_tile_kernel(CovArgs g)
+{
+    constexpr int T = 8;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int snap = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (snap >= g.n_out) return;
+    const size_t base = (size_t)snap * (size_t)g.S;
+    const float2 *pa[T], *pb[T];
+#pragma unroll
+    for (int i = 0; i < T; i++) {
+        pa[i] = g.in[(g.a0 + i < g.n_ch) ? g.a0 + i : 0] + base;
+        pb[i] = g.in[(g.b0 + i < g.n_ch) ? g.b0 + i : 0] + base;
+    }
+    float re[T][T], im[T][T];
+#pragma unroll
+    for (int a = 0; a < T; a++)
+#pragma unroll
+        for (int b = 0; b < T; b++) { re[a][b] = 0.f; im[a][b] = 0.f; }
+
+    auto mac = [&](const float2 (&xa)[T], const float2 (&xb)[T]) {
+#pragma unroll
+        for (int a = 0; a < T; a++)
+#pragma unroll
+            for (int b = 0; b < T; b++) {
+                re[a][b] = fmaf(xa[a].x, xb[b].x, fmaf(xa[a].y, xb[b].y, re[a][b]));
+                im[a][b] = fmaf(xa[a].y, xb[b].x, fmaf(-xa[a].x, xb[b].y, im[a][b]));
+            }
+    };
+    if constexpr (VEC2) {
+        const int npair = g.K >> 1;
+        for (int p = lane; p < npair; p += kWave) {
+            float2 xa0[T], xa1[T], xb0[T], xb1[T];
+#pragma unroll
+            for (int i = 0; i < T; i++) {
+                float4 va = *reinterpret_cast<const float4 *>(pa[i] + 2 * (size_t)p);
+                float4 vb = *reinterpret_cast<const float4 *>(pb[i] + 2 * (size_t)p);
+                xa0[i] = make_float2(va.x, va.y); xa1[i] = make_float2(va.z, va.w);
+                xb0[i] = make_float2(vb.x, vb.y); xb1[i] = make_float2(vb.z, vb.w);
+            }
+            mac(xa0, xb0);
+            mac(xa1, xb1);
+        }
+        if ((g.K & 1) && lane == 0) {
+            float2 xa[T], xb[T];
+#pragma unroll
+            for (int i = 0; i < T; i++) { xa[i] = pa[i][g.K - 1]; xb[i] = pb[i][g.K - 1]; }
+            mac(xa, xb);
+        }
+    } else {
+        for (int t = lane; t < g.K; t += kWave) {
+            float2 xa[T], xb[T];
+#pragma unroll
+            for (int i = 0; i < T; i++) { xa[i] = pa[i][t]; xb[i] = pb[i][t]; }
+            mac(xa, xb);
+        }
+    }
+    float2 r = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < T; a++)
+#pragma unroll
+        for (int b = 0; b < T; b++) {
+            const float sr = wave_allreduce_sum(re[a][b]);
+            const float si = wave_allreduce_sum(im[a][b]);
+            if (lane == a + b * T) r = make_float2(sr, si);
+        }
+    r.x = __fmul_rn(r.x, g.inv_k);
+    r.y = __fmul_rn(r.y, g.inv_k);
+    const int a = g.a0 + (lane & (T - 1)), b = g.b0 + (lane >> 3);
+    if (a < g.n_ch && b < g.n_ch) {
+        float2 *item = g.out + (size_t)snap * g.n_ch * g.n_ch;
+        item[a + (size_t)b * g.n_ch] = r;
+        if (g.a0 != g.b0) item[b + (size_t)a * g.n_ch] = make_float2(r.x, -r.y);
+    }
+}
+
+// R <- 0.5 R + (0.5/K) conj(R[N-1-a, N-1-b]), pairwise in place (element e with N^2-1-e).
+__global__ void cov_fb_kernel(float2 *out, int nn, long long n_items, float fb_hk)
+{
+    const int half = (nn + 1) / 2;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_items * half) return;
+    const long long item = gid / half;
+    const int e = (int)(gid - item * half), e2 = nn - 1 - e;
+    float2 *p = out + item * nn;
+    const float2 u = p[e], v = p[e2];
+    float2 nu, nv;
+    nu.x = __fadd_rn(__fmul_rn(0.5f, u.x), __fmul_rn(fb_hk, v.x));
+    nu.y = __fadd_rn(__fmul_rn(0.5f, u.y), __fmul_rn(fb_hk, -v.y));
+    nv.x = __fadd_rn(__fmul_rn(0.5f, v.x), __fmul_rn(fb_hk, u.x));
+    nv.y = __fadd_rn(__fmul_rn(0.5f, v.y), __fmul_rn(fb_hk, -u.y));
+    p[e] = nu;
+    if (e2 != e) p[e2] = nv;
+}
+
+template <int TN> static void launch_wave(const CovArgs &g, bool vec2, hipStream_t st)
+{
+    const int waves_per_block = 4;
+    dim3 grid((g.n_out + waves_per_block - 1) / waves_per_block), block(waves_per_block * kWave);
+    if (vec2)
+        hipLaunchKernelGGL((cov_wave_kernel<TN, true>), grid, block, 0, st, g);
+    else
+        hipLaunchKernelGGL((cov_wave_kernel<TN, false>), grid, block, 0, st, g);
+}
+
+// Launches K1 on `st`.  d_in: N device pointers.  Returns DOA_OK / error.
+int launch_autocorrelate(int N, int K, int ovl, int avg, int n_out, const void *const *d_in, void *d_out,
+                         hipStream_t st)
+{
+    if (n_out <= 0) return DOA_OK;
+    CovArgs g;
+    memset(&g, 0, sizeof g);
+    bool vec2 = ((K - ovl) % 2 == 0);
+    for (int k = 0; k < N; k++) {
+        g.in[k] = static_cast<const float2 *>(d_in[k]);
+        if (!d_in[k]) { set_error("autocorrelate: input stream %d is NULL", k); return DOA_ERR_INVALID_ARG; }
+        if (reinterpret_cast<uintptr_t>(d_in[k]) % 8) { set_error("autocorrelate: input stream %d is not 8-byte aligned", k); return DOA_ERR_INVALID_ARG; }
+        if (reinterpret_cast<uintptr_t>(d_in[k]) % 16) vec2 = false;
+    }
+    for (int k = N; k < DOA_MAX_ANT_ELE; k++) g.in[k] = g.in[0];
+    g.out = static_cast<float2 *>(d_out);
+    g.n_ch = N; g.K = K; g.S = K - ovl; g.n_out = n_out; g.avg = avg;
+    g.inv_k = (float)(1.0 / K);
+    g.fb_hk = (float)(0.5 / K);
+    switch (N) {
+    case 1: launch_wave<1>(g, vec2, st); break;
+    case 2: launch_wave<2>(g, vec2, st); break;
+    case 3: launch_wave<3>(g, vec2, st); break;
+    case 4: launch_wave<4>(g, vec2, st); break;
+    case 5: launch_wave<5>(g, vec2, st); break;
+    case 6: launch_wave<6>(g, vec2, st); break;
+    case 7: launch_wave<7>(g, vec2, st); break;
+    case 8: launch_wave<8>(g, vec2, st); break;
+    default: {
+        dim3 grid((n_out + 3) / 4), block(256);
+        for (int a0 = 0; a0 < N; a0 += 8)
+            for (int b0 = a0; b0 < N; b0 += 8) {
+                g.a0 = a0; g.b0 = b0;
+                if (vec2) hipLaunchKernelGGL(cov_tile_kernel<true>, grid, block, 0, st, g);
+                else      hipLaunchKernelGGL(cov_tile_kernel<false>, grid, block, 0, st, g);
+            }
+        if (avg == 1) {
+            const int nn = N * N, half = (nn + 1) / 2;
+            const long long total = (long long)n_out * half;
+            hipLaunchKernelGGL(cov_fb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g.out, nn,
+                               (long long)n_out, g.fb_hk);
+        }
+    }
+    }
+    DOA_HIP_TRY(hipGetLastError());
+    return DOA_OK;
+}
+
+}  // namespace doa
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+struct doa_autocorrelate {
+    int inputs, snapshot, overlap, avg;
+    int device;
+    hipStream_t stream = nullptr;
+    doa::DevBuf d_in, d_out;
+};
+
+extern "C" {
+
+doa_autocorrelate_t *doa_autocorrelate_create(int inputs, int snapshot_size, int overlap_size, int avg_method)
+{
+    doa::clear_error();
+    // grc/doa_autocorrelate.xml:41-43 checks; the C++ ctor of the reference does not validate, so a
+    // violating call would read/write out of bounds there — here it fails in create.
+    if (inputs <= 0 || snapshot_size <= 0 || overlap_size < 0 || overlap_size >= snapshot_size) {
+        doa::set_error("autocorrelate: need inputs > 0, snapshot_size > 0, 0 <= overlap_size < snapshot_size "
+                       "(got %d, %d, %d)", inputs, snapshot_size, overlap_size);
+        return nullptr;
+    }
+    if (inputs > DOA_MAX_ANT_ELE) {
+        doa::set_error("autocorrelate: inputs=%d exceeds DOA_MAX_ANT_ELE=%d", inputs, DOA_MAX_ANT_ELE);
+        return nullptr;
+    }
+    int dev = 0;
+    if (doa::ensure_device(&dev) != DOA_OK) return nullptr;
+    auto *h = new (std::nothrow) doa_autocorrelate();
+    if (!h) { doa::set_error("out of memory"); return nullptr; }
+    h->inputs = inputs; h->snapshot = snapshot_size; h->overlap = overlap_size; h->avg = avg_method;
+    h->device = dev;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        doa::set_error("autocorrelate: hipStreamCreate failed");
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+void doa_autocorrelate_destroy(doa_autocorrelate_t *h)
+{
+    if (!h) return;
+    h->d_in.release();
+    h->d_out.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int doa_autocorrelate_history(const doa_autocorrelate_t *h) { return h ? h->overlap + 1 : DOA_ERR_INVALID_ARG; }
+
+int doa_autocorrelate_forecast(const doa_autocorrelate_t *h, int noutput_items)
+{
+    if (!h || noutput_items < 0) return DOA_ERR_INVALID_ARG;
+    return (h->snapshot - h->overlap) * noutput_items;
+}
+
+long long doa_autocorrelate_input_span(const doa_autocorrelate_t *h, int noutput_items)
+{
+    if (!h || noutput_items <= 0) return 0;
+    return (long long)(noutput_items - 1) * (h->snapshot - h->overlap) + h->snapshot;
+}
+
+int doa_autocorrelate_work_dev(doa_autocorrelate_t *h, int noutput_items, const void *const *d_input_items,
+                               void *d_output_items0, void *hip_stream)
+{
+    doa::clear_error();
+    if (!h || noutput_items < 0 || !d_input_items || (!d_output_items0 && noutput_items > 0)) {
+        doa::set_error("autocorrelate_work_dev: bad arguments");
+        return DOA_ERR_INVALID_ARG;
+    }
+    int rc = doa::launch_autocorrelate(h->inputs, h->snapshot, h->overlap, h->avg, noutput_items, d_input_items,
+                                       d_output_items0, static_cast<hipStream_t>(hip_stream));
+    return rc == DOA_OK ? noutput_items : rc;
+}
+
+int doa_autocorrelate_work(doa_autocorrelate_t *h, int noutput_items, const void *const *input_items,
+                           void *output_items0)
+{
+    doa::clear_error();
+    if (!h || noutput_items < 0 || !input_items || (!output_items0 && noutput_items > 0)) {
+        doa::set_error("autocorrelate_work: bad arguments");
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (noutput_items == 0) return 0;
+    const int N = h->inputs;
+    const size_t span = (size_t)doa_autocorrelate_input_span(h, noutput_items);
+    const size_t span_al = (span + 1) & ~(size_t)1;  // keep every stream 16-B aligned on the device
+    int rc = h->d_in.reserve(span_al * N * sizeof(float2));
+    if (rc != DOA_OK) return rc;
+    const size_t out_bytes = (size_t)noutput_items * N * N * sizeof(float2);
+    rc = h->d_out.reserve(out_bytes);
+    if (rc != DOA_OK) return rc;
+    const void *d_ptrs[DOA_MAX_ANT_ELE];
+    for (int k = 0; k < N; k++) {
+        if (!input_items[k]) { doa::set_error("autocorrelate_work: input_items[%d] is NULL", k); return DOA_ERR_INVALID_ARG; }
+        float2 *dst = h->d_in.as<float2>() + k * span_al;
+        DOA_HIP_TRY(hipMemcpyAsync(dst, input_items[k], span * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        d_ptrs[k] = dst;
+    }
+    rc = doa::launch_autocorrelate(N, h->snapshot, h->overlap, h->avg, noutput_items, d_ptrs, h->d_out.p, h->stream);
+    if (rc != DOA_OK) return rc;
+    DOA_HIP_TRY(hipMemcpyAsync(output_items0, h->d_out.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    DOA_HIP_TRY(hipStreamSynchronize(h->stream));
+    return noutput_items;
+}
+
+}  // extern "C"

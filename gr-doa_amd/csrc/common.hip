@@ -1,0 +1,107 @@
+// common.hip — error state, device binding and buffer helpers of libdoa_hip.so.
+#include "common.hpp"
+
+#include <atomic>
+
+namespace doa {
+
+static thread_local char g_err[512] = "";
+static std::atomic<int> g_evd_bits{64};
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+void clear_error() { g_err[0] = '\0'; }
+
+int ensure_device(int *device_out)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); libdoa_hip has no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        (void)hipGetLastError();
+        return DOA_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    DOA_HIP_TRY(hipGetDevice(&dev));
+    if (device_out) *device_out = dev;
+    return DOA_OK;
+}
+
+int DevBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap) return DOA_OK;
+    if (p) {
+        DOA_HIP_TRY(hipFree(p));
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes + bytes / 4;  // amortise growth
+    if (want < 4096) want = 4096;
+    DOA_HIP_TRY(hipMalloc(&p, want));
+    cap = want;
+    return DOA_OK;
+}
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+int PinnedBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap) return DOA_OK;
+    if (p) {
+        DOA_HIP_TRY(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes + bytes / 4;
+    if (want < 4096) want = 4096;
+    DOA_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return DOA_OK;
+}
+void PinnedBuf::release()
+{
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+int evd_precision_bits() { return g_evd_bits.load(); }
+
+}  // namespace doa
+
+extern "C" {
+
+const char *doa_last_error(void) { return doa::g_err; }
+int doa_hip_abi_version(void) { return 1; }
+
+int doa_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int doa_set_evd_precision(int bits)
+{
+    if (bits != 32 && bits != 64) {
+        doa::set_error("doa_set_evd_precision: bits must be 32 or 64 (got %d)", bits);
+        return DOA_ERR_INVALID_ARG;
+    }
+    doa::g_evd_bits.store(bits);
+    return DOA_OK;
+}
+int doa_get_evd_precision(void) { return doa::g_evd_bits.load(); }
+
+}  // extern "C"

@@ -1,0 +1,412 @@
+// find_local_max.hip — K5: top-M local maxima of a float vector and their x-axis locations.
+//
+// Replaces gr::doa::find_local_max (reference lib/find_local_max_impl.cc:47-194, _impl.h:53-58):
+//   s = sign(diff(v)); zeros ("flats") take, right to left, the sign of their right neighbour
+//   (>= 0 -> +1, else -1; a flat at the very end becomes +1) (:89-107); peaks are the i with
+//   s[i-1] = +1, s[i] = -1 (:114; end points never qualify); peaks are ranked by value, descending
+//   (:135-137); fewer than M peaks -> the remaining slots repeat an index (:145-163, including the
+//   reference's use of the best peak's *position in the peak list* as that index); M == 1 is the
+//   global arg-max (_impl.h:53-56).  Port 0 = v[pk] in rank order, port 1 = sort(x_axis[pk],
+//   "descend") (:186-188) on the float-accumulated x axis (:60-69).
+// Integer/compare logic only: results are bit-identical to the oracle for identical inputs (ties
+// between equal peak values are ordered lowest index first; the reference leaves them unspecified).
+//
+// Kernel shape: one wave per vector, the vector in registers as CH float4 per lane (position
+// p = 256 j + 4 lane + e, i.e. 1 KiB contiguous per load instruction).  Neighbour signs cross
+// lanes by shuffles; flats (rare) are resolved by a ballot-based suffix scan in position order;
+// the top-M are M rounds of a wave arg-max.  Vector lengths that are not a multiple of 4 or exceed
+// 4096 take a one-thread-per-vector fallback that walks the reference's steps literally.
+#include "kernels.hpp"
+
+#include <climits>
+#include <vector>
+
+namespace doa {
+
+int PeakTables::build(int num_max_vals, int vector_len, float x_min_, float x_max_)
+{
+    M = num_max_vals; L = vector_len; x_min = x_min_; x_max = x_max_;
+    std::vector<float> x(L);
+    x[0] = x_min;
+    float x_prev = x_min;
+    const float x_range = x_max - x_min;
+    for (int ii = 1; ii < L; ii++) {           // lib/find_local_max_impl.cc:60-69, all in float
+        float v = x_prev + x_range / L;
+        x_prev = v;
+        x[ii] = v;
+    }
+    int rc = d_x.reserve(sizeof(float) * (size_t)L);
+    if (rc != DOA_OK) return rc;
+    DOA_HIP_TRY(hipMemcpy(d_x.p, x.data(), sizeof(float) * (size_t)L, hipMemcpyHostToDevice));
+    return DOA_OK;
+}
+
+// (value, index) ordering used for ranking: larger value first, then lower index; idx == INT_MAX
+// marks "no candidate".
+__device__ __forceinline__ bool cand_better(float v, int i, float bv, int bi)
+{
+    if (i == INT_MAX) return false;
+    if (bi == INT_MAX) return true;
+    return (v > bv) || (v == bv && i < bi);
+}
+__device__ __forceinline__ void wave_argbest(float &v, int &i)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(v, m, kWave);
+        const int oi = __shfl_xor(i, m, kWave);
+        if (cand_better(ov, oi, v, i)) { v = ov; i = oi; }
+    }
+}
+__device__ __forceinline__ int wave_sum_int(int x)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, kWave);
+    return x;
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void find_local_max_kernel(const float *__restrict__ in, const float *__restrict__ xaxis,
+                                                             float *__restrict__ out_val, float *__restrict__ out_loc,
+                                                             int L, int M, int n_items)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
+    if (item >= n_items) return;
+    const float *v_in = in + (size_t)item * L;
+
+    float v[CH][4];
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+        const int p0 = 256 * j + 4 * lane;
+        if (p0 < L) {   // L % 4 == 0: a float4 is entirely inside or outside
+            const float4 t = *reinterpret_cast<const float4 *>(v_in + p0);
+            v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
+        } else {
+            v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+        }
+    }
+
+    int sel_idx = INT_MAX;      // lane r keeps the r-th ranked index
+    float sel_val = 0.f;
+    int n_valid = 0, best_list_pos = 0;
+
+    if (M > 1) {
+        // --- sign of the first-order difference; positions past the last difference act as +1 ---
+        int s[CH][4];
+        bool flat_here = false;
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            float nxt_first = __shfl_down(v[j][0], 1, kWave);                 // lane+1, e=0, same chunk
+            const float wrap = (j + 1 < CH) ? __shfl(v[(j + 1 < CH) ? j + 1 : j][0], 0, kWave) : 0.f;
+            if (lane == kWave - 1) nxt_first = wrap;                          // lane 0 of the next chunk
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int p = 256 * j + 4 * lane + e;
+                const float nx = (e < 3) ? v[j][e + 1] : nxt_first;
+                if (p < L - 1) {
+                    const float d = nx - v[j][e];
+                    s[j][e] = (d > 0.f) ? 1 : ((d < 0.f) ? -1 : 0);
+                    flat_here |= (s[j][e] == 0);
+                } else {
+                    s[j][e] = 1;
+                }
+            }
+        }
+        // --- flats: suffix scan in position order (chunk, lane, e), last chunk first ---
+        if (__any(flat_here)) {
+            int chunk_carry = 1;  // sign taken by a flat that runs to the end of the vector
+#pragma unroll
+            for (int j = CH - 1; j >= 0; j--) {
+                int f = 0;
+#pragma unroll
+                for (int e = 3; e >= 0; e--) f = (s[j][e] != 0) ? s[j][e] : f;   // first non-zero of this lane
+                const unsigned long long nz = __ballot(f != 0), pos = __ballot(f > 0);
+                const unsigned long long above = (lane == kWave - 1) ? 0ull : (nz >> (lane + 1));
+                int carry = chunk_carry;
+                if (above) {
+                    const int src = lane + 1 + __builtin_ctzll(above);
+                    carry = ((pos >> src) & 1ull) ? 1 : -1;
+                }
+#pragma unroll
+                for (int e = 3; e >= 0; e--) {
+                    if (s[j][e] == 0) s[j][e] = carry;
+                    carry = s[j][e];
+                }
+                chunk_carry = __shfl(s[j][0], 0, kWave);
+            }
+        }
+        // --- peaks: s[p-1] == +1 and s[p] == -1 ---
+        unsigned long long pk = 0;   // bit (4*j+e)
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            int prev_last = __shfl_up(s[j][3], 1, kWave);                      // lane-1, e=3
+            const int wrap = (j > 0) ? __shfl(s[(j > 0) ? j - 1 : 0][3], kWave - 1, kWave) : 0;
+            if (lane == 0) prev_last = wrap;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int p = 256 * j + 4 * lane + e;
+                const int sp = (e > 0) ? s[j][e - 1] : prev_last;
+                if (p >= 1 && p <= L - 2 && sp == 1 && s[j][e] == -1) pk |= 1ull << (4 * j + e);
+            }
+        }
+        n_valid = wave_sum_int(__popcll(pk));
+        // --- top-M by value (descending), ties -> lowest index ---
+        const int rounds = (n_valid < M) ? n_valid : M;
+        for (int r = 0; r < rounds; r++) {
+            float bv = 0.f;
+            int bi = INT_MAX;
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if ((pk >> (4 * j + e)) & 1ull) {
+                        const int p = 256 * j + 4 * lane + e;
+                        if (cand_better(v[j][e], p, bv, bi)) { bv = v[j][e]; bi = p; }
+                    }
+            wave_argbest(bv, bi);
+            if (r == 0) {
+                // position of the best peak inside the ascending peak list (= #peaks before it)
+                int before = 0;
+#pragma unroll
+                for (int j = 0; j < CH; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (((pk >> (4 * j + e)) & 1ull) && (256 * j + 4 * lane + e) < bi) before++;
+                best_list_pos = wave_sum_int(before);
+            }
+            // owner drops the winner from its candidate set
+            if (bi != INT_MAX && ((bi & 255) >> 2) == lane) pk &= ~(1ull << (4 * (bi >> 8) + (bi & 3)));
+            if (lane == r) { sel_idx = bi; sel_val = bv; }
+        }
+    }
+
+    // --- fill slots / M == 1: indices that are not ranked peaks ---
+    int fill_idx = 0;
+    if (M == 1 || n_valid == 0) {
+        // arma index_max (op_max::direct_max): best starts at -inf, an element replaces it only if
+        // strictly greater -> first occurrence of the maximum, NaNs never win, nothing > -inf -> 0
+        float bv = 0.f;
+        int bi = INT_MAX;
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int p = 256 * j + 4 * lane + e;
+                if (p < L && v[j][e] > -INFINITY && cand_better(v[j][e], p, bv, bi)) { bv = v[j][e]; bi = p; }
+            }
+        wave_argbest(bv, bi);
+        fill_idx = (bi == INT_MAX) ? 0 : bi;
+    } else {
+        fill_idx = best_list_pos;   // reference quirk: list position used as a vector index (:153,160)
+    }
+    if (lane < M) {
+        int idx;
+        float val;
+        if (M > 1 && lane < n_valid) { idx = sel_idx; val = sel_val; }
+        else { idx = fill_idx; val = v_in[fill_idx]; }
+        const float x = xaxis[idx];
+        out_val[(size_t)item * M + lane] = val;
+        // descending sort of the M locations: rank = number of entries that must precede this one
+        int rank = 0;
+        for (int k = 0; k < M; k++) {
+            const float xk = __shfl(x, k, kWave);
+            rank += (xk > x || (xk == x && k < lane)) ? 1 : 0;
+        }
+        out_loc[(size_t)item * M + rank] = x;
+    }
+}
+
+// Literal walk of the reference's steps, one thread per vector (any L >= 1).  `scratch` holds L
+// signed bytes per item.
+__global__ void find_local_max_serial_kernel(const float *__restrict__ in, const float *__restrict__ xaxis,
+                                             float *__restrict__ out_val, float *__restrict__ out_loc,
+                                             signed char *__restrict__ scratch, int L, int M, int n_items)
+{
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_items) return;
+    const float *v = in + (size_t)item * L;
+    signed char *s = scratch + (size_t)item * L;
+    int pkidx[DOA_MAX_PEAKS];
+    auto argmax_first = [&]() {   // arma index_max semantics, see the wave kernel
+        int k = 0;
+        float best = -INFINITY;
+        for (int i = 0; i < L; i++) if (v[i] > best) { best = v[i]; k = i; }
+        return k;
+    };
+    if (M == 1 || L < 3) {
+        const int k = argmax_first();
+        for (int j = 0; j < M; j++) pkidx[j] = k;
+    } else {
+        const int Ls = L - 1;
+        for (int i = 0; i < Ls; i++) { const float d = v[i + 1] - v[i]; s[i] = (d > 0.f) ? 1 : ((d < 0.f) ? -1 : 0); }
+        for (int i = Ls - 1; i >= 0; i--)
+            if (s[i] == 0) { const int nx = (i + 1 < Ls - 1) ? i + 1 : Ls - 1; s[i] = (s[nx] >= 0) ? 1 : -1; }
+        int n_valid = 0;
+        for (int i = 1; i < Ls; i++) if (s[i - 1] == 1 && s[i] == -1) n_valid++;
+        const int rounds = n_valid < M ? n_valid : M;
+        int best_list_pos = 0;
+        for (int r = 0; r < rounds; r++) {
+            int bi = -1;
+            for (int i = 1; i < Ls; i++)
+                if (s[i - 1] == 1 && s[i] == -1) {
+                    bool used = false;
+                    for (int u = 0; u < r; u++) used |= (pkidx[u] == i);
+                    if (!used && (bi < 0 || v[i] > v[bi])) bi = i;
+                }
+            pkidx[r] = bi;
+            if (r == 0)
+                for (int i = 1; i < bi; i++) if (s[i - 1] == 1 && s[i] == -1) best_list_pos++;
+        }
+        const int fill = (n_valid == 0) ? argmax_first() : best_list_pos;
+        for (int j = rounds; j < M; j++) pkidx[j] = fill;
+    }
+    float loc[DOA_MAX_PEAKS];
+    for (int j = 0; j < M; j++) { out_val[(size_t)item * M + j] = v[pkidx[j]]; loc[j] = xaxis[pkidx[j]]; }
+    for (int a = 1; a < M; a++) {
+        const float t = loc[a];
+        int b = a - 1;
+        while (b >= 0 && loc[b] < t) { loc[b + 1] = loc[b]; b--; }
+        loc[b + 1] = t;
+    }
+    for (int j = 0; j < M; j++) out_loc[(size_t)item * M + j] = loc[j];
+}
+
+
+
+int launch_find_local_max(const PeakTables &t, int n_items, const void *d_in, void *d_max, void *d_argmax,
+                          hipStream_t st)
+{
+    if (n_items <= 0) return DOA_OK;
+    const int L = t.L, M = t.M;
+    const float *in = (const float *)d_in;
+    const float *x = t.d_x.as<float>();
+    float *ov = (float *)d_max, *ol = (float *)d_argmax;
+    const bool fast = (L % 4 == 0) && L >= 4 && L <= 4096 && (reinterpret_cast<uintptr_t>(d_in) % 16 == 0);
+    if (!fast) {
+        set_error("find_local_max: vector_len=%d needs the serial path (call through a handle)", L);
+        return DOA_ERR_UNSUPPORTED;
+    }
+    dim3 block(256), grid((n_items + 3) / 4);
+    if (L <= 256)       hipLaunchKernelGGL(find_local_max_kernel<1>, grid, block, 0, st, in, x, ov, ol, L, M, n_items);
+    else if (L <= 512)  hipLaunchKernelGGL(find_local_max_kernel<2>, grid, block, 0, st, in, x, ov, ol, L, M, n_items);
+    else if (L <= 1024) hipLaunchKernelGGL(find_local_max_kernel<4>, grid, block, 0, st, in, x, ov, ol, L, M, n_items);
+    else if (L <= 2048) hipLaunchKernelGGL(find_local_max_kernel<8>, grid, block, 0, st, in, x, ov, ol, L, M, n_items);
+    else                hipLaunchKernelGGL(find_local_max_kernel<16>, grid, block, 0, st, in, x, ov, ol, L, M, n_items);
+    DOA_HIP_TRY(hipGetLastError());
+    return DOA_OK;
+}
+
+int launch_find_local_max_serial(const PeakTables &t, int n_items, const void *d_in, void *d_max, void *d_argmax,
+                                 void *d_scratch, hipStream_t st)
+{
+    if (n_items <= 0) return DOA_OK;
+    hipLaunchKernelGGL(find_local_max_serial_kernel, dim3((n_items + 63) / 64), dim3(64), 0, st, (const float *)d_in,
+                       t.d_x.as<float>(), (float *)d_max, (float *)d_argmax, (signed char *)d_scratch, t.L, t.M,
+                       n_items);
+    DOA_HIP_TRY(hipGetLastError());
+    return DOA_OK;
+}
+
+bool find_local_max_fast_ok(int L, const void *d_in)
+{
+    return (L % 4 == 0) && L >= 4 && L <= 4096 && (reinterpret_cast<uintptr_t>(d_in) % 16 == 0);
+}
+
+}  // namespace doa
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+struct doa_find_local_max {
+    doa::PeakTables tab;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    doa::DevBuf d_in, d_out0, d_out1, d_scratch;
+};
+
+extern "C" {
+
+doa_find_local_max_t *doa_find_local_max_create(int num_max_vals, int vector_len, float x_min, float x_max)
+{
+    doa::clear_error();
+    // grc/doa_find_local_max.xml:33-35
+    if (num_max_vals <= 0 || vector_len <= 0 || !(x_max > x_min)) {
+        doa::set_error("find_local_max: need num_max_vals > 0, vector_len > 0, x_max > x_min (got %d, %d, %g, %g)",
+                       num_max_vals, vector_len, (double)x_min, (double)x_max);
+        return nullptr;
+    }
+    if (num_max_vals > DOA_MAX_PEAKS) {
+        doa::set_error("find_local_max: num_max_vals=%d exceeds DOA_MAX_PEAKS=%d", num_max_vals, DOA_MAX_PEAKS);
+        return nullptr;
+    }
+    int dev = 0;
+    if (doa::ensure_device(&dev) != DOA_OK) return nullptr;
+    auto *h = new (std::nothrow) doa_find_local_max();
+    if (!h) { doa::set_error("out of memory"); return nullptr; }
+    h->device = dev;
+    if (h->tab.build(num_max_vals, vector_len, x_min, x_max) != DOA_OK ||
+        hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        if (!*doa_last_error()) doa::set_error("find_local_max: device setup failed");
+        doa_find_local_max_destroy(h);
+        return nullptr;
+    }
+    return h;
+}
+
+void doa_find_local_max_destroy(doa_find_local_max_t *h)
+{
+    if (!h) return;
+    h->tab.release();
+    h->d_in.release(); h->d_out0.release(); h->d_out1.release(); h->d_scratch.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int doa_find_local_max_work_dev(doa_find_local_max_t *h, int noutput_items, const void *d_input_items0,
+                                void *d_output_items0, void *d_output_items1, void *hip_stream)
+{
+    doa::clear_error();
+    if (!h || noutput_items < 0 || (noutput_items > 0 && (!d_input_items0 || !d_output_items0 || !d_output_items1))) {
+        doa::set_error("find_local_max_work_dev: bad arguments");
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (noutput_items == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    int rc;
+    if (doa::find_local_max_fast_ok(h->tab.L, d_input_items0)) {
+        rc = doa::launch_find_local_max(h->tab, noutput_items, d_input_items0, d_output_items0, d_output_items1, st);
+    } else {
+        rc = h->d_scratch.reserve((size_t)noutput_items * h->tab.L);
+        if (rc == DOA_OK)
+            rc = doa::launch_find_local_max_serial(h->tab, noutput_items, d_input_items0, d_output_items0,
+                                                   d_output_items1, h->d_scratch.p, st);
+    }
+    return rc == DOA_OK ? noutput_items : rc;
+}
+
+int doa_find_local_max_work(doa_find_local_max_t *h, int noutput_items, const void *input_items0, void *output_items0,
+                            void *output_items1)
+{
+    doa::clear_error();
+    if (!h || noutput_items < 0 || (noutput_items > 0 && (!input_items0 || !output_items0 || !output_items1))) {
+        doa::set_error("find_local_max_work: bad arguments");
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (noutput_items == 0) return 0;
+    const size_t in_bytes = (size_t)noutput_items * h->tab.L * sizeof(float);
+    const size_t out_bytes = (size_t)noutput_items * h->tab.M * sizeof(float);
+    int rc = h->d_in.reserve(in_bytes);
+    if (rc == DOA_OK) rc = h->d_out0.reserve(out_bytes);
+    if (rc == DOA_OK) rc = h->d_out1.reserve(out_bytes);
+    if (rc != DOA_OK) return rc;
+    DOA_HIP_TRY(hipMemcpyAsync(h->d_in.p, input_items0, in_bytes, hipMemcpyHostToDevice, h->stream));
+    rc = doa_find_local_max_work_dev(h, noutput_items, h->d_in.p, h->d_out0.p, h->d_out1.p, h->stream);
+    if (rc < 0) return rc;
+    DOA_HIP_TRY(hipMemcpyAsync(output_items0, h->d_out0.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    DOA_HIP_TRY(hipMemcpyAsync(output_items1, h->d_out1.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    DOA_HIP_TRY(hipStreamSynchronize(h->stream));
+    return noutput_items;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// kernels.hpp — launch entry points shared between the per-block C-ABI files and the pipeline.
+#pragma once
+#include "common.hpp"
+
+namespace doa {
+
+// K1  (autocorrelate.hip)
+int launch_autocorrelate(int N, int K, int ovl, int avg, int n_out, const void *const *d_in, void *d_out,
+                         hipStream_t st);
+
+// Host-built tables of MUSIC_lin_array (music.hip): z_i = exp(j*psi_i), psi_i = k_i * d with
+// k_i = float(-2*pi*cos(theta_i)) on the reference's float-accumulated theta grid.
+struct MusicTables {
+    int N = 0, M = 0, P = 0;
+    float norm_spacing = 0.f;
+    DevBuf d_z;  // P float2
+    int build(float norm_spacing, int num_targets, int num_ant_ele, int pspectrum_len);
+    void release() { d_z.release(); }
+};
+
+// coefficient record per item: [u0, Re u1, Im u1, ..., Re u_{N-1}, Im u_{N-1}, pad] = 2N floats
+inline int coef_stride(int N) { return 2 * N; }
+
+// K2+K3: batched Hermitian EVD + noise projector + diagonal sums.  d_pn may be NULL.
+int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_pn, int evd_bits,
+                     hipStream_t st);
+// K4: spectrum scan.  d_q (un-normalised null spectrum, P floats per item) may be NULL.
+int launch_music_scan(const MusicTables &t, int n_items, const void *d_coef, void *d_spec, void *d_q,
+                      hipStream_t st);
+
+// K5 (find_local_max.hip)
+struct PeakTables {
+    int M = 0, L = 0;
+    float x_min = 0.f, x_max = 0.f;
+    DevBuf d_x;  // L floats, float-accumulated x axis
+    int build(int num_max_vals, int vector_len, float x_min, float x_max);
+    void release() { d_x.release(); }
+};
+int launch_find_local_max(const PeakTables &t, int n_items, const void *d_in, void *d_max, void *d_argmax,
+                          hipStream_t st);
+
+// K6 (root_music.hip): polynomial roots from the coefficient records -> angles.
+int launch_root_music(int N, int M, float norm_spacing, int n_items, const void *d_coef, void *d_out,
+                      void *d_status, hipStream_t st);
+
+}  // namespace doa

@@ -1,0 +1,577 @@
+// music.hip — K2+K3 (batched Hermitian EVD -> noise projector -> diagonal sums) and K4 (pseudo-
+// spectrum scan) of MUSIC_lin_array on gfx950.
+//
+// Replaces gr::doa::MUSIC_lin_array (reference lib/MUSIC_lin_array_impl.cc):
+//   ctor  :47-87,98-104  element positions, float-accumulated theta grid, steering vectors
+//   work  :121-144       eig_sym (LAPACK cheevd 'V','U', ascending) -> U_N = first N-M vectors
+//                        -> P_N = U_N U_N^H -> out[i] = 1/Re(a_i^H P_N a_i) -> 10 log10(out/max)
+//
+// How it is laid out here:
+//   * EVD (music_evd_kernel): one lane per covariance matrix.  Cyclic complex Jacobi on the full
+//     Hermitian matrix held in registers (N <= 4, fully unrolled) or per-lane scratch (N <= 16),
+//     in double by default (float selectable: doa_set_evd_precision).  Rotations are built from
+//     rsqrt only, so J is unitary to working precision.  Epilogue: rank eigenvalues ascending,
+//     P_N = sum over the N-M smallest of v v^H, and the 2N-1 diagonal sums
+//         u_l = sum_r P_N[r+l, r]   (u_0 real, u_l complex)
+//     written as one 8N-byte record per item (and P_N itself when asked for).  These u_l are exactly
+//     the Root-MUSIC polynomial coefficients (lib/rootMUSIC_linear_array_impl.cc:74-79).
+//   * Scan (music_scan_kernel): for a ULA a_i^H P_N a_i is Hermitian-Toeplitz in the element index,
+//         Q(psi_i) = u_0 + 2 Re sum_{l=1}^{N-1} u_l z_i^l,   z_i = exp(j psi_i), psi_i = k_i d,
+//     so each angle costs N-1 complex Horner steps instead of N^2+N complex MACs; that drops the
+//     kernel below the fp32 ridge (HBM-bound: 8N B in, 4P B out per item).  One wave owns one item:
+//     each lane evaluates 4 consecutive angles per 256-angle chunk (z_i stays in registers across
+//     items), the item maximum is a wave all-reduce, and each store instruction writes 1 KiB
+//     contiguous.  Values match the reference's a^H P a up to fp32 rounding (~1e-7 relative).
+#include "kernels.hpp"
+
+#include <cmath>
+#include <vector>
+
+namespace doa {
+
+// ---------------------------------------------------------------------------------------------
+// host-side tables (constructor work of the reference block)
+// ---------------------------------------------------------------------------------------------
+int MusicTables::build(float norm_spacing_, int num_targets, int num_ant_ele, int pspectrum_len)
+{
+    N = num_ant_ele; M = num_targets; P = pspectrum_len; norm_spacing = norm_spacing_;
+    // theta grid: float accumulator, sum formed in double (lib/MUSIC_lin_array_impl.cc:64-72)
+    std::vector<float> theta(P);
+    theta[0] = 0.0f;
+    float theta_prev = 0.0f;
+    for (int ii = 1; ii < P; ii++) {
+        float th = (float)(theta_prev + 180.0 / P);
+        theta_prev = th;
+        theta[ii] = (float)(M_PI * th / 180.0);
+    }
+    // amv (:98-104): phase_n = float(-2 pi cos(theta)) * loc_n with loc_n = d*0.5*(N-1-2n); the
+    // phase step between neighbouring elements is psi = k*d.  z = exp(j psi) in double -> float.
+    std::vector<float2> z(P);
+    const double d = (double)norm_spacing;
+    for (int ii = 0; ii < P; ii++) {
+        const float k = (float)(-1.0 * 2 * M_PI * std::cos((double)theta[ii]));
+        const double psi = (double)k * d;
+        z[ii] = make_float2((float)std::cos(psi), (float)std::sin(psi));
+    }
+    int rc = d_z.reserve(sizeof(float2) * (size_t)P);
+    if (rc != DOA_OK) return rc;
+    DOA_HIP_TRY(hipMemcpy(d_z.p, z.data(), sizeof(float2) * (size_t)P, hipMemcpyHostToDevice));
+    return DOA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2+K3: batched Hermitian Jacobi EVD, projector, diagonal sums
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Real;
+template <> struct Real<float> {
+    static __device__ __forceinline__ float rsqrt(float x)
+    {
+        float y = __builtin_amdgcn_rsqf(x);
+        float e = fmaf(-x * y, y, 1.0f);
+        return fmaf(0.5f * y, e, y);
+    }
+    static constexpr float tol = 6e-14f;     // (off-norm / diag-norm)^2 at convergence, ~4 eps^2
+    static constexpr float tiny = 1e-36f;
+    static constexpr float tau_max = 1e15f;
+    static constexpr int max_sweeps = 10;
+};
+template <> struct Real<double> {
+    static __device__ __forceinline__ double rsqrt(double x)
+    {
+        double y = __builtin_amdgcn_rsq(x);
+        double e = fma(-x * y, y, 1.0);
+        y = fma(0.5 * y, e, y);
+        e = fma(-x * y, y, 1.0);
+        return fma(0.5 * y, e, y);
+    }
+    static constexpr double tol = 2e-31;
+    static constexpr double tiny = 1e-290;
+    static constexpr double tau_max = 1e140;
+    static constexpr int max_sweeps = 14;
+};
+
+// A (Hermitian, full storage) and V live in ar/ai/vr/vi; on return A is diagonal to working
+// precision and the columns of V are the eigenvectors.
+template <int N, typename T, bool UNROLL>
+__device__ __forceinline__ void herm_jacobi(T (&ar)[N][N], T (&ai)[N][N], T (&vr)[N][N], T (&vi)[N][N])
+{
+    constexpr int U = UNROLL ? N : 1;
+    const int max_sweeps = (N <= 4) ? Real<T>::max_sweeps : Real<T>::max_sweeps + 2 * N;
+    for (int sweep = 0; sweep < max_sweeps; sweep++) {
+        T off = 0, dg = 0;
+#pragma unroll U
+        for (int p = 0; p < N; p++) {
+            dg = fma(ar[p][p], ar[p][p], dg);
+#pragma unroll U
+            for (int q = 0; q < N; q++)
+                if (q > p) off += ar[p][q] * ar[p][q] + ai[p][q] * ai[p][q];
+        }
+        if (!(off > Real<T>::tol * dg) || !(off > Real<T>::tiny)) break;
+#pragma unroll U
+        for (int p = 0; p < N - 1; p++) {
+#pragma unroll U
+            for (int q = 1; q < N; q++) {
+                if (q <= p) continue;
+                const T apr = ar[p][q], api = ai[p][q];
+                const T g2 = apr * apr + api * api;
+                if (!(g2 > Real<T>::tiny)) continue;
+                const T inv_g = Real<T>::rsqrt(g2);
+                const T phr = apr * inv_g, phi = api * inv_g;          // e^{j phi}
+                T tau = (ar[q][q] - ar[p][p]) * (T)0.5 * inv_g;
+                tau = fmin(fmax(tau, -Real<T>::tau_max), Real<T>::tau_max);
+                const T x1 = fma(tau, tau, (T)1);
+                const T r = x1 * Real<T>::rsqrt(x1);                    // sqrt(1+tau^2)
+                const T h = fabs(tau) + r;                              // 1/|t|
+                const T w = Real<T>::rsqrt(fma(h, h, (T)1));
+                const T c = h * w;
+                const T s = copysign(w, tau);
+                const T spr = s * phr, spi = s * phi;                   // J[p][q] = s e^{j phi}
+                // columns p,q:  A <- A J      (J[p][p]=J[q][q]=c, J[q][p] = -conj(J[p][q]))
+#pragma unroll U
+                for (int k = 0; k < N; k++) {
+                    const T kpr = ar[k][p], kpi = ai[k][p], kqr = ar[k][q], kqi = ai[k][q];
+                    ar[k][p] = c * kpr - (spr * kqr + spi * kqi);
+                    ai[k][p] = c * kpi - (spr * kqi - spi * kqr);
+                    ar[k][q] = c * kqr + (spr * kpr - spi * kpi);
+                    ai[k][q] = c * kqi + (spr * kpi + spi * kpr);
+                }
+                // rows p,q:  A <- J^H A
+#pragma unroll U
+                for (int k = 0; k < N; k++) {
+                    const T pkr = ar[p][k], pki = ai[p][k], qkr = ar[q][k], qki = ai[q][k];
+                    ar[p][k] = c * pkr - (spr * qkr - spi * qki);
+                    ai[p][k] = c * pki - (spr * qki + spi * qkr);
+                    ar[q][k] = c * qkr + (spr * pkr + spi * pki);
+                    ai[q][k] = c * qki + (spr * pki - spi * pkr);
+                }
+                ar[p][q] = 0; ai[p][q] = 0; ar[q][p] = 0; ai[q][p] = 0;
+                ai[p][p] = 0; ai[q][q] = 0;
+                // V <- V J
+#pragma unroll U
+                for (int k = 0; k < N; k++) {
+                    const T kpr = vr[k][p], kpi = vi[k][p], kqr = vr[k][q], kqi = vi[k][q];
+                    vr[k][p] = c * kpr - (spr * kqr + spi * kqi);
+                    vi[k][p] = c * kpi - (spr * kqi - spi * kqr);
+                    vr[k][q] = c * kqr + (spr * kpr - spi * kpi);
+                    vi[k][q] = c * kqi + (spr * kpi + spi * kpr);
+                }
+            }
+        }
+    }
+}
+
+template <int N, typename T>
+__global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
+                                                       float2 *__restrict__ pn_out, int n_items, int M)
+{
+    constexpr bool UNROLL = (N <= 4);
+    constexpr int U = UNROLL ? N : 1;
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_items) return;
+    const float2 *Ri = R + (size_t)item * (N * N);
+
+    T ar[N][N], ai[N][N], vr[N][N], vi[N][N];
+    // only the upper triangle of the item is significant (cheevd uplo='U'); element (r,c) at r + c*N
+#pragma unroll U
+    for (int c = 0; c < N; c++) {
+#pragma unroll U
+        for (int r = 0; r < N; r++) {
+            if (r > c) continue;
+            const float2 x = Ri[r + c * N];
+            if (r == c) { ar[r][c] = (T)x.x; ai[r][c] = 0; }
+            else { ar[r][c] = (T)x.x; ai[r][c] = (T)x.y; ar[c][r] = (T)x.x; ai[c][r] = -(T)x.y; }
+        }
+    }
+#pragma unroll U
+    for (int r = 0; r < N; r++)
+#pragma unroll U
+        for (int c = 0; c < N; c++) { vr[r][c] = (r == c) ? (T)1 : (T)0; vi[r][c] = 0; }
+
+    herm_jacobi<N, T, UNROLL>(ar, ai, vr, vi);
+
+    // ascending rank of each eigenvalue (eig_sym contract); noise set = ranks < N-M
+    T sel[N];
+#pragma unroll U
+    for (int i = 0; i < N; i++) {
+        int rank = 0;
+#pragma unroll U
+        for (int j = 0; j < N; j++) {
+            const bool before = (ar[j][j] < ar[i][i]) || (ar[j][j] == ar[i][i] && j < i);
+            rank += before ? 1 : 0;
+        }
+        sel[i] = (rank < N - M) ? (T)1 : (T)0;
+    }
+    // P_N[a][b] = sum_i sel_i v[a][i] conj(v[b][i]); reuse ar/ai for P_N
+#pragma unroll U
+    for (int a = 0; a < N; a++) {
+#pragma unroll U
+        for (int b = 0; b < N; b++) {
+            T pr = 0, pi = 0;
+#pragma unroll U
+            for (int i = 0; i < N; i++) {
+                pr += sel[i] * (vr[a][i] * vr[b][i] + vi[a][i] * vi[b][i]);
+                pi += sel[i] * (vi[a][i] * vr[b][i] - vr[a][i] * vi[b][i]);
+            }
+            ar[a][b] = pr; ai[a][b] = pi;
+        }
+    }
+    if (pn_out) {
+        float2 *po = pn_out + (size_t)item * (N * N);
+#pragma unroll U
+        for (int c = 0; c < N; c++)
+#pragma unroll U
+            for (int r = 0; r < N; r++) po[r + c * N] = make_float2((float)ar[r][c], (float)ai[r][c]);
+    }
+    // diagonal sums u_l = sum_r P_N[r+l][r]
+    float *co = coef + (size_t)item * (2 * N);
+#pragma unroll U
+    for (int l = 0; l < N; l++) {
+        T ur = 0, ui = 0;
+#pragma unroll U
+        for (int r = 0; r < N; r++)
+            if (r + l < N) { ur += ar[r + l][r]; ui += ai[r + l][r]; }
+        if (l == 0) co[0] = (float)ur;
+        else { co[2 * l - 1] = (float)ur; co[2 * l] = (float)ui; }
+    }
+    co[2 * N - 1] = 0.f;
+}
+
+template <int N> static void launch_evd_n(int M, int n_items, const void *d_R, void *d_coef, void *d_pn, int bits,
+                                          hipStream_t st)
+{
+    dim3 block(64), grid((n_items + 63) / 64);
+    if (bits == 32)
+        hipLaunchKernelGGL((music_evd_kernel<N, float>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,
+                           (float2 *)d_pn, n_items, M);
+    else
+        hipLaunchKernelGGL((music_evd_kernel<N, double>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,
+                           (float2 *)d_pn, n_items, M);
+}
+
+int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_pn, int evd_bits,
+                     hipStream_t st)
+{
+    if (n_items <= 0) return DOA_OK;
+    switch (N) {
+#define DOA_EVD_CASE(n) case n: launch_evd_n<n>(M, n_items, d_R, d_coef, d_pn, evd_bits, st); break;
+        DOA_EVD_CASE(2) DOA_EVD_CASE(3) DOA_EVD_CASE(4) DOA_EVD_CASE(5) DOA_EVD_CASE(6) DOA_EVD_CASE(7)
+        DOA_EVD_CASE(8) DOA_EVD_CASE(9) DOA_EVD_CASE(10) DOA_EVD_CASE(11) DOA_EVD_CASE(12) DOA_EVD_CASE(13)
+        DOA_EVD_CASE(14) DOA_EVD_CASE(15) DOA_EVD_CASE(16)
+#undef DOA_EVD_CASE
+    default:
+        set_error("MUSIC: num_ant_ele=%d outside the built range 2..%d", N, DOA_MAX_ANT_ELE);
+        return DOA_ERR_UNSUPPORTED;
+    }
+    DOA_HIP_TRY(hipGetLastError());
+    return DOA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: spectrum scan
+// ---------------------------------------------------------------------------------------------
+// Q = u0 + 2 Re( sum_{l=1}^{N-1} u_l z^l ) by Horner.  co points at the item's coefficient record.
+template <int N> __device__ __forceinline__ float null_spectrum(const float *__restrict__ co, float zr, float zi)
+{
+    if constexpr (N == 1) return co[0];
+    float hr = co[2 * (N - 1) - 1], hi = co[2 * (N - 1)];
+#pragma unroll
+    for (int l = N - 2; l >= 1; l--) {
+        const float tr = fmaf(hr, zr, fmaf(-hi, zi, co[2 * l - 1]));
+        const float ti = fmaf(hr, zi, fmaf(hi, zr, co[2 * l]));
+        hr = tr; hi = ti;
+    }
+    const float re = fmaf(hr, zr, -hi * zi);
+    return fmaf(2.0f, re, co[0]);
+}
+
+__device__ __forceinline__ float db_from_ratio(float out, float mx, float inv_mx)
+{
+    // 10*log10(out/max): the maximum itself must come out as exactly 0 dB (x/x == 1 in the
+    // reference), everything else as out * (1/max) through the hardware log2.
+    float ratio = (out == mx) ? 1.0f : out * inv_mx;
+    return 3.0102999566398120f * __log2f(ratio);
+}
+
+// Fast path: P % 4 == 0 and P <= 256*CH.  One wave per item, grid-stride over items so that the
+// z table (4*CH angles per lane) is loaded once per wave.
+template <int N, int CH>
+__global__ __launch_bounds__(256) void music_scan_kernel(const float *__restrict__ coef, const float2 *__restrict__ ztab,
+                                                         float *__restrict__ spec, float *__restrict__ qout, int P,
+                                                         int n_items)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const int n_waves = gridDim.x * (blockDim.x / kWave);
+
+    float zr[CH][4], zi[CH][4];
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+        const int i0 = 4 * lane + 256 * j;
+        if (i0 < P) {
+            const float4 a = *reinterpret_cast<const float4 *>(ztab + i0);
+            const float4 b = *reinterpret_cast<const float4 *>(ztab + i0 + 2);
+            zr[j][0] = a.x; zi[j][0] = a.y; zr[j][1] = a.z; zi[j][1] = a.w;
+            zr[j][2] = b.x; zi[j][2] = b.y; zr[j][3] = b.z; zi[j][3] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { zr[j][e] = 1.f; zi[j][e] = 0.f; }
+        }
+    }
+    for (int item = wave; item < n_items; item += n_waves) {
+        const float *co = coef + (size_t)item * (2 * N);   // wave-uniform -> scalar loads
+        float c[2 * N];
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) c[k] = co[k];
+        float out[CH][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const bool live = (4 * lane + 256 * j) < P;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float q = null_spectrum<N>(c, zr[j][e], zi[j][e]);
+                if (qout && live) qout[(size_t)item * P + 4 * lane + 256 * j + e] = q;
+                out[j][e] = __builtin_amdgcn_rcpf(q);           // 1.0/Q
+                if (live) mx = fmaxf(mx, out[j][e]);
+            }
+        }
+        mx = wave_allreduce_max(mx);
+        const float inv_mx = __builtin_amdgcn_rcpf(mx);
+        float *row = spec + (size_t)item * P;
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const int i0 = 4 * lane + 256 * j;
+            if (i0 < P) {
+                float4 v;
+                v.x = db_from_ratio(out[j][0], mx, inv_mx);
+                v.y = db_from_ratio(out[j][1], mx, inv_mx);
+                v.z = db_from_ratio(out[j][2], mx, inv_mx);
+                v.w = db_from_ratio(out[j][3], mx, inv_mx);
+                *reinterpret_cast<float4 *>(row + i0) = v;
+            }
+        }
+    }
+}
+
+// Any P: one wave per item, one angle per lane per step, two passes (max, then write).
+template <int N>
+__global__ __launch_bounds__(256) void music_scan_generic_kernel(const float *__restrict__ coef,
+                                                                 const float2 *__restrict__ ztab, float *__restrict__ spec,
+                                                                 float *__restrict__ qout, int P, int n_items)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const int n_waves = gridDim.x * (blockDim.x / kWave);
+    for (int item = wave; item < n_items; item += n_waves) {
+        const float *co = coef + (size_t)item * (2 * N);
+        float c[2 * N];
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) c[k] = co[k];
+        float mx = -INFINITY;
+        for (int i = lane; i < P; i += kWave) {
+            const float2 z = ztab[i];
+            const float q = null_spectrum<N>(c, z.x, z.y);
+            if (qout) qout[(size_t)item * P + i] = q;
+            mx = fmaxf(mx, __builtin_amdgcn_rcpf(q));
+        }
+        mx = wave_allreduce_max(mx);
+        const float inv_mx = __builtin_amdgcn_rcpf(mx);
+        for (int i = lane; i < P; i += kWave) {
+            const float2 z = ztab[i];
+            const float o = __builtin_amdgcn_rcpf(null_spectrum<N>(c, z.x, z.y));
+            spec[(size_t)item * P + i] = db_from_ratio(o, mx, inv_mx);
+        }
+    }
+}
+
+template <int N> static void launch_scan_n(const MusicTables &t, int n_items, const void *d_coef, void *d_spec,
+                                           void *d_q, hipStream_t st)
+{
+    const int P = t.P;
+    const float *co = (const float *)d_coef;
+    const float2 *z = t.d_z.as<float2>();
+    float *sp = (float *)d_spec, *q = (float *)d_q;
+    const int waves_per_block = 4;
+    const bool aligned = (P % 4 == 0) && (reinterpret_cast<uintptr_t>(d_spec) % 16 == 0);
+    // enough waves to fill the chip several times over, but few enough that each wave amortises its
+    // z-table load over several items
+    int blocks = (n_items + waves_per_block - 1) / waves_per_block;
+    const int max_blocks = 256 * 8;
+    if (blocks > max_blocks) blocks = max_blocks;
+    dim3 grid(blocks), block(waves_per_block * kWave);
+    if (aligned && P <= 256)
+        hipLaunchKernelGGL((music_scan_kernel<N, 1>), grid, block, 0, st, co, z, sp, q, P, n_items);
+    else if (aligned && P <= 512)
+        hipLaunchKernelGGL((music_scan_kernel<N, 2>), grid, block, 0, st, co, z, sp, q, P, n_items);
+    else if (aligned && P <= 1024)
+        hipLaunchKernelGGL((music_scan_kernel<N, 4>), grid, block, 0, st, co, z, sp, q, P, n_items);
+    else if (aligned && P <= 2048)
+        hipLaunchKernelGGL((music_scan_kernel<N, 8>), grid, block, 0, st, co, z, sp, q, P, n_items);
+    else if (aligned && P <= 4096)
+        hipLaunchKernelGGL((music_scan_kernel<N, 16>), grid, block, 0, st, co, z, sp, q, P, n_items);
+    else
+        hipLaunchKernelGGL((music_scan_generic_kernel<N>), grid, block, 0, st, co, z, sp, q, P, n_items);
+}
+
+int launch_music_scan(const MusicTables &t, int n_items, const void *d_coef, void *d_spec, void *d_q, hipStream_t st)
+{
+    if (n_items <= 0) return DOA_OK;
+    switch (t.N) {
+#define DOA_SCAN_CASE(n) case n: launch_scan_n<n>(t, n_items, d_coef, d_spec, d_q, st); break;
+        DOA_SCAN_CASE(2) DOA_SCAN_CASE(3) DOA_SCAN_CASE(4) DOA_SCAN_CASE(5) DOA_SCAN_CASE(6) DOA_SCAN_CASE(7)
+        DOA_SCAN_CASE(8) DOA_SCAN_CASE(9) DOA_SCAN_CASE(10) DOA_SCAN_CASE(11) DOA_SCAN_CASE(12) DOA_SCAN_CASE(13)
+        DOA_SCAN_CASE(14) DOA_SCAN_CASE(15) DOA_SCAN_CASE(16)
+#undef DOA_SCAN_CASE
+    default:
+        set_error("MUSIC: num_ant_ele=%d outside the built range 2..%d", t.N, DOA_MAX_ANT_ELE);
+        return DOA_ERR_UNSUPPORTED;
+    }
+    DOA_HIP_TRY(hipGetLastError());
+    return DOA_OK;
+}
+
+}  // namespace doa
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+struct doa_MUSIC_lin_array {
+    doa::MusicTables tab;
+    int evd_bits = 64;
+    int device = 0;
+    long long items_total = 0;
+    hipStream_t stream = nullptr;
+    doa::DevBuf d_in, d_out, d_coef, d_pn, d_q;
+};
+
+static int music_validate(const char *who, float norm_spacing, int num_targets, int num_ant_ele)
+{
+    // grc/doa_MUSIC_lin_array.xml:33-35 (inputs > 0, inputs > num_targets, norm_spacing <= 0.5); the
+    // reference ctor does not validate (num_targets >= N would index cols(0,-1)), so create fails here.
+    if (num_ant_ele <= 0 || num_targets <= 0 || num_targets >= num_ant_ele) {
+        doa::set_error("%s: need 0 < num_targets < num_ant_ele (got %d, %d)", who, num_targets, num_ant_ele);
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (!(norm_spacing > 0.0f) || norm_spacing > 0.5f) {
+        doa::set_error("%s: need 0 < norm_spacing <= 0.5 (got %g)", who, (double)norm_spacing);
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (num_ant_ele > DOA_MAX_ANT_ELE) {
+        doa::set_error("%s: num_ant_ele=%d exceeds DOA_MAX_ANT_ELE=%d", who, num_ant_ele, DOA_MAX_ANT_ELE);
+        return DOA_ERR_UNSUPPORTED;
+    }
+    return DOA_OK;
+}
+
+extern "C" {
+
+doa_MUSIC_lin_array_t *doa_MUSIC_lin_array_create(float norm_spacing, int num_targets, int num_ant_ele,
+                                                  int pspectrum_len)
+{
+    doa::clear_error();
+    if (music_validate("MUSIC_lin_array", norm_spacing, num_targets, num_ant_ele) != DOA_OK) return nullptr;
+    if (pspectrum_len <= 0) {
+        doa::set_error("MUSIC_lin_array: pspectrum_len must be > 0 (got %d)", pspectrum_len);
+        return nullptr;
+    }
+    int dev = 0;
+    if (doa::ensure_device(&dev) != DOA_OK) return nullptr;
+    auto *h = new (std::nothrow) doa_MUSIC_lin_array();
+    if (!h) { doa::set_error("out of memory"); return nullptr; }
+    h->device = dev;
+    h->evd_bits = doa::evd_precision_bits();
+    if (h->tab.build(norm_spacing, num_targets, num_ant_ele, pspectrum_len) != DOA_OK ||
+        hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        if (!*doa_last_error()) doa::set_error("MUSIC_lin_array: device setup failed");
+        doa_MUSIC_lin_array_destroy(h);
+        return nullptr;
+    }
+    return h;
+}
+
+void doa_MUSIC_lin_array_destroy(doa_MUSIC_lin_array_t *h)
+{
+    if (!h) return;
+    h->tab.release();
+    h->d_in.release(); h->d_out.release(); h->d_coef.release(); h->d_pn.release(); h->d_q.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+long long doa_MUSIC_lin_array_items_total(const doa_MUSIC_lin_array_t *h) { return h ? h->items_total : 0; }
+
+int doa_MUSIC_lin_array_work_dev(doa_MUSIC_lin_array_t *h, int noutput_items, const void *d_input_items0,
+                                 void *d_output_items0, void *hip_stream)
+{
+    doa::clear_error();
+    if (!h || noutput_items < 0 || (noutput_items > 0 && (!d_input_items0 || !d_output_items0))) {
+        doa::set_error("MUSIC_lin_array_work_dev: bad arguments");
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (noutput_items == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const int N = h->tab.N;
+    int rc = h->d_coef.reserve((size_t)noutput_items * doa::coef_stride(N) * sizeof(float));
+    if (rc != DOA_OK) return rc;
+    rc = doa::launch_music_evd(N, h->tab.M, noutput_items, d_input_items0, h->d_coef.p, nullptr, h->evd_bits, st);
+    if (rc != DOA_OK) return rc;
+    rc = doa::launch_music_scan(h->tab, noutput_items, h->d_coef.p, d_output_items0, nullptr, st);
+    if (rc != DOA_OK) return rc;
+    h->items_total += noutput_items;
+    return noutput_items;
+}
+
+int doa_MUSIC_lin_array_work(doa_MUSIC_lin_array_t *h, int noutput_items, const void *input_items0,
+                             void *output_items0)
+{
+    doa::clear_error();
+    if (!h || noutput_items < 0 || (noutput_items > 0 && (!input_items0 || !output_items0))) {
+        doa::set_error("MUSIC_lin_array_work: bad arguments");
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (noutput_items == 0) return 0;
+    const int N = h->tab.N, P = h->tab.P;
+    const size_t in_bytes = (size_t)noutput_items * N * N * sizeof(float2);
+    const size_t out_bytes = (size_t)noutput_items * P * sizeof(float);
+    int rc = h->d_in.reserve(in_bytes);
+    if (rc == DOA_OK) rc = h->d_out.reserve(out_bytes);
+    if (rc != DOA_OK) return rc;
+    DOA_HIP_TRY(hipMemcpyAsync(h->d_in.p, input_items0, in_bytes, hipMemcpyHostToDevice, h->stream));
+    rc = doa_MUSIC_lin_array_work_dev(h, noutput_items, h->d_in.p, h->d_out.p, h->stream);
+    if (rc < 0) return rc;
+    DOA_HIP_TRY(hipMemcpyAsync(output_items0, h->d_out.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    DOA_HIP_TRY(hipStreamSynchronize(h->stream));
+    return noutput_items;
+}
+
+int doa_MUSIC_lin_array_debug(doa_MUSIC_lin_array_t *h, int noutput_items, const void *input_items0,
+                              void *projector_out, void *null_spectrum_out)
+{
+    doa::clear_error();
+    if (!h || noutput_items <= 0 || !input_items0) {
+        doa::set_error("MUSIC_lin_array_debug: bad arguments");
+        return DOA_ERR_INVALID_ARG;
+    }
+    const int N = h->tab.N, P = h->tab.P;
+    const size_t in_bytes = (size_t)noutput_items * N * N * sizeof(float2);
+    const size_t sp_bytes = (size_t)noutput_items * P * sizeof(float);
+    int rc = h->d_in.reserve(in_bytes);
+    if (rc == DOA_OK) rc = h->d_out.reserve(sp_bytes);
+    if (rc == DOA_OK) rc = h->d_q.reserve(sp_bytes);
+    if (rc == DOA_OK) rc = h->d_pn.reserve(in_bytes);
+    if (rc == DOA_OK) rc = h->d_coef.reserve((size_t)noutput_items * doa::coef_stride(N) * sizeof(float));
+    if (rc != DOA_OK) return rc;
+    DOA_HIP_TRY(hipMemcpyAsync(h->d_in.p, input_items0, in_bytes, hipMemcpyHostToDevice, h->stream));
+    rc = doa::launch_music_evd(N, h->tab.M, noutput_items, h->d_in.p, h->d_coef.p, h->d_pn.p, h->evd_bits, h->stream);
+    if (rc != DOA_OK) return rc;
+    rc = doa::launch_music_scan(h->tab, noutput_items, h->d_coef.p, h->d_out.p, h->d_q.p, h->stream);
+    if (rc != DOA_OK) return rc;
+    if (projector_out)
+        DOA_HIP_TRY(hipMemcpyAsync(projector_out, h->d_pn.p, in_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (null_spectrum_out)
+        DOA_HIP_TRY(hipMemcpyAsync(null_spectrum_out, h->d_q.p, sp_bytes, hipMemcpyDeviceToHost, h->stream));
+    DOA_HIP_TRY(hipStreamSynchronize(h->stream));
+    return noutput_items;
+}
+
+}  // extern "C"

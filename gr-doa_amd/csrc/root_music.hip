@@ -1,0 +1,274 @@
+// root_music.hip — K6: Root-MUSIC for a uniform linear array on gfx950.
+//
+// Replaces gr::doa::rootMUSIC_linear_array (reference lib/rootMUSIC_linear_array_impl.cc:46-152):
+//   EVD + noise projector as MUSIC (:108-116; here K2+K3 of music.hip), then
+//   u[k], k = 0..2N-2: sums of the diagonals of P_N (:68-79), roots of sum_k u[k] z^k — the
+//   reference gets them as eigenvalues of the Frobenius companion matrix through LAPACK cgeev
+//   (:80-86) — keep the roots strictly inside the unit circle (:122-127), take the num_targets
+//   closest to it (:131-141), angle = acos(arg(z) / (2 pi d)) in degrees, sorted ascending (:144).
+//
+// Here the roots come from a batched Aberth-Ehrlich iteration in double, one lane per item (the
+// polynomial has degree 2N-2 <= 30, a few hundred flops per sweep).  Root-MUSIC's root pairs
+// (z, 1/conj(z)) sit within ~1e-4 of each other at the unit circle, which is why a float solver
+// (the reference's cgeev) is itself only ~0.01 degree accurate; see DESIGN.md "parity".
+// Edge cases follow the reference: with fewer than num_targets interior roots the missing slots
+// come out as 90 degrees (arg(inf+0i) = 0, :135-141); with none, the reference raises inside
+// Armadillo (index_min on an empty vector) — here the item's status word is set and its angles
+// are NaN, and the host entry point returns DOA_ERR_NUMERIC.
+#include "kernels.hpp"
+
+namespace doa {
+
+template <int N, bool UNROLL>
+__device__ __forceinline__ void aberth_roots(const double (&cr)[2 * N - 1], const double (&ci)[2 * N - 1],
+                                             double (&zr)[2 * N - 2], double (&zi)[2 * N - 2])
+{
+    constexpr int D = 2 * N - 2;
+    constexpr int U = UNROLL ? D : 1;
+    // start: points of unequal radius around the unit circle (an exactly circular start is a fixed
+    // configuration for this conjugate-reciprocal polynomial)
+#pragma unroll U
+    for (int k = 0; k < D; k++) {
+        const double ang = 2.0 * M_PI * (k + 0.37) / D;
+        const double rad = 0.75 + 0.5 * ((k * 0.6180339887498949) - floor(k * 0.6180339887498949));
+        double s, c;
+        sincos(ang, &s, &c);
+        zr[k] = rad * c; zi[k] = rad * s;
+    }
+    for (int it = 0; it < 100; it++) {
+        double worst = 0.0;
+#pragma unroll U
+        for (int k = 0; k < D; k++) {
+            // Horner for p and p' at z_k
+            double pr = cr[D], pi = ci[D], dr = 0.0, di = 0.0;
+#pragma unroll U
+            for (int m = D - 1; m >= 0; m--) {
+                const double ndr = dr * zr[k] - di * zi[k] + pr;
+                const double ndi = dr * zi[k] + di * zr[k] + pi;
+                dr = ndr; di = ndi;
+                const double npr = pr * zr[k] - pi * zi[k] + cr[m];
+                const double npi = pr * zi[k] + pi * zr[k] + ci[m];
+                pr = npr; pi = npi;
+            }
+            // w = p/p'
+            const double dn = dr * dr + di * di;
+            double wr, wi;
+            if (dn > 0.0) { wr = (pr * dr + pi * di) / dn; wi = (pi * dr - pr * di) / dn; }
+            else { wr = 1e-3; wi = 1e-3; }
+            // s = sum_{j != k} 1/(z_k - z_j)
+            double sr = 0.0, si = 0.0;
+#pragma unroll U
+            for (int j = 0; j < D; j++) {
+                if (j == k) continue;
+                const double er = zr[k] - zr[j], ei = zi[k] - zi[j];
+                const double en = er * er + ei * ei;
+                if (en > 0.0) { sr += er / en; si -= ei / en; }
+            }
+            // delta = w / (1 - w s)
+            const double qr = 1.0 - (wr * sr - wi * si), qi = -(wr * si + wi * sr);
+            const double qn = qr * qr + qi * qi;
+            double er = wr, ei = wi;
+            if (qn > 0.0) { er = (wr * qr + wi * qi) / qn; ei = (wi * qr - wr * qi) / qn; }
+            zr[k] -= er; zi[k] -= ei;
+            const double rel = (er * er + ei * ei) / (1.0 + zr[k] * zr[k] + zi[k] * zi[k]);
+            worst = fmax(worst, rel);
+        }
+        if (worst < 1e-30) break;
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void root_music_kernel(const float *__restrict__ coef, float *__restrict__ out,
+                                                        int *__restrict__ status, int n_items, int M, double two_pi_d)
+{
+    constexpr bool UNROLL = (N <= 4);
+    constexpr int D = 2 * N - 2;
+    constexpr int U = UNROLL ? D : 1;
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_items) return;
+    const float *co = coef + (size_t)item * (2 * N);
+    // polynomial c[k], k = 0..2N-2: c[N-1-l] = u_l, c[N-1+l] = conj(u_l)   (:71-78)
+    double cr[2 * N - 1], ci[2 * N - 1];
+    cr[N - 1] = (double)co[0]; ci[N - 1] = 0.0;
+#pragma unroll U
+    for (int l = 1; l < N; l++) {
+        const double ur = (double)co[2 * l - 1], ui = (double)co[2 * l];
+        cr[N - 1 - l] = ur; ci[N - 1 - l] = ui;
+        cr[N - 1 + l] = ur; ci[N - 1 + l] = -ui;
+    }
+    double zr[D], zi[D];
+    aberth_roots<N, UNROLL>(cr, ci, zr, zi);
+
+    // dist = 1 - |z|, keep dist > 0, pick the M smallest, one at a time (:122-141)
+    double dist[D];
+    int n_inside = 0;
+#pragma unroll U
+    for (int k = 0; k < D; k++) {
+        dist[k] = 1.0 - sqrt(zr[k] * zr[k] + zi[k] * zi[k]);
+        if (!(dist[k] > 0.0)) dist[k] = -1.0;   // outside: excluded
+        else n_inside++;
+    }
+    float *o = out + (size_t)item * M;
+    if (n_inside == 0) {
+        if (status) status[item] = 1;
+        for (int j = 0; j < M; j++) o[j] = __builtin_nanf("");
+        return;
+    }
+    if (status) status[item] = 0;
+    float aoa[DOA_MAX_PEAKS];
+    for (int j = 0; j < M; j++) {
+        int best = -1;
+#pragma unroll U
+        for (int k = 0; k < D; k++)
+            if (dist[k] > 0.0 && (best < 0 || dist[k] < dist[best])) best = k;
+        double ang = 0.0;                         // exhausted: arg(inf + 0i) = 0 -> 90 degrees
+        if (best >= 0) {
+            double br = 0.0, bi = 0.0;
+#pragma unroll U
+            for (int k = 0; k < D; k++) if (k == best) { br = zr[k]; bi = zi[k]; dist[k] = -1.0; }
+            ang = atan2(bi, br);
+        }
+        aoa[j] = (float)(180.0 * acos(ang / two_pi_d) / M_PI);
+    }
+    for (int a = 1; a < M; a++) {                 // ascending (:144); NaNs keep their slots
+        const float t = aoa[a];
+        int b = a - 1;
+        while (b >= 0 && aoa[b] > t) { aoa[b + 1] = aoa[b]; b--; }
+        aoa[b + 1] = t;
+    }
+    for (int j = 0; j < M; j++) o[j] = aoa[j];
+}
+
+int launch_root_music(int N, int M, float norm_spacing, int n_items, const void *d_coef, void *d_out, void *d_status,
+                      hipStream_t st)
+{
+    if (n_items <= 0) return DOA_OK;
+    const double two_pi_d = 2 * M_PI * (double)norm_spacing;   // 2*datum::pi*d_norm_spacing, float promoted (:135)
+    dim3 block(64), grid((n_items + 63) / 64);
+    switch (N) {
+#define DOA_ROOT_CASE(n)                                                                                   \
+    case n:                                                                                                \
+        hipLaunchKernelGGL(root_music_kernel<n>, grid, block, 0, st, (const float *)d_coef, (float *)d_out, \
+                           (int *)d_status, n_items, M, two_pi_d);                                         \
+        break;
+        DOA_ROOT_CASE(2) DOA_ROOT_CASE(3) DOA_ROOT_CASE(4) DOA_ROOT_CASE(5) DOA_ROOT_CASE(6) DOA_ROOT_CASE(7)
+        DOA_ROOT_CASE(8) DOA_ROOT_CASE(9) DOA_ROOT_CASE(10) DOA_ROOT_CASE(11) DOA_ROOT_CASE(12) DOA_ROOT_CASE(13)
+        DOA_ROOT_CASE(14) DOA_ROOT_CASE(15) DOA_ROOT_CASE(16)
+#undef DOA_ROOT_CASE
+    default:
+        set_error("rootMUSIC: num_ant_ele=%d outside the built range 2..%d", N, DOA_MAX_ANT_ELE);
+        return DOA_ERR_UNSUPPORTED;
+    }
+    DOA_HIP_TRY(hipGetLastError());
+    return DOA_OK;
+}
+
+}  // namespace doa
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+struct doa_rootMUSIC_linear_array {
+    float norm_spacing = 0.f;
+    int M = 0, N = 0;
+    int evd_bits = 64;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    doa::DevBuf d_in, d_out, d_coef, d_status;
+    doa::PinnedBuf h_status;
+};
+
+extern "C" {
+
+doa_rootMUSIC_linear_array_t *doa_rootMUSIC_linear_array_create(float norm_spacing, int num_targets, int num_ant_ele)
+{
+    doa::clear_error();
+    // grc/doa_rootMUSIC_linear_array.xml:28-30
+    if (num_ant_ele <= 0 || num_targets <= 0 || num_targets >= num_ant_ele) {
+        doa::set_error("rootMUSIC_linear_array: need 0 < num_targets < num_ant_ele (got %d, %d)", num_targets, num_ant_ele);
+        return nullptr;
+    }
+    if (!(norm_spacing > 0.0f) || norm_spacing > 0.5f) {
+        doa::set_error("rootMUSIC_linear_array: need 0 < norm_spacing <= 0.5 (got %g)", (double)norm_spacing);
+        return nullptr;
+    }
+    if (num_ant_ele > DOA_MAX_ANT_ELE || num_targets > DOA_MAX_PEAKS) {
+        doa::set_error("rootMUSIC_linear_array: num_ant_ele=%d / num_targets=%d exceed the built caps (%d / %d)",
+                       num_ant_ele, num_targets, DOA_MAX_ANT_ELE, DOA_MAX_PEAKS);
+        return nullptr;
+    }
+    int dev = 0;
+    if (doa::ensure_device(&dev) != DOA_OK) return nullptr;
+    auto *h = new (std::nothrow) doa_rootMUSIC_linear_array();
+    if (!h) { doa::set_error("out of memory"); return nullptr; }
+    h->norm_spacing = norm_spacing; h->M = num_targets; h->N = num_ant_ele; h->device = dev;
+    h->evd_bits = doa::evd_precision_bits();
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        doa::set_error("rootMUSIC_linear_array: hipStreamCreate failed");
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+void doa_rootMUSIC_linear_array_destroy(doa_rootMUSIC_linear_array_t *h)
+{
+    if (!h) return;
+    h->d_in.release(); h->d_out.release(); h->d_coef.release(); h->d_status.release(); h->h_status.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int doa_rootMUSIC_linear_array_work_dev(doa_rootMUSIC_linear_array_t *h, int noutput_items, const void *d_input_items0,
+                                        void *d_output_items0, void *hip_stream)
+{
+    doa::clear_error();
+    if (!h || noutput_items < 0 || (noutput_items > 0 && (!d_input_items0 || !d_output_items0))) {
+        doa::set_error("rootMUSIC_linear_array_work_dev: bad arguments");
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (noutput_items == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    int rc = h->d_coef.reserve((size_t)noutput_items * doa::coef_stride(h->N) * sizeof(float));
+    if (rc == DOA_OK) rc = h->d_status.reserve((size_t)noutput_items * sizeof(int));
+    if (rc != DOA_OK) return rc;
+    rc = doa::launch_music_evd(h->N, h->M, noutput_items, d_input_items0, h->d_coef.p, nullptr, h->evd_bits, st);
+    if (rc != DOA_OK) return rc;
+    rc = doa::launch_root_music(h->N, h->M, h->norm_spacing, noutput_items, h->d_coef.p, d_output_items0,
+                                h->d_status.p, st);
+    return rc == DOA_OK ? noutput_items : rc;
+}
+
+int doa_rootMUSIC_linear_array_work(doa_rootMUSIC_linear_array_t *h, int noutput_items, const void *input_items0,
+                                    void *output_items0)
+{
+    doa::clear_error();
+    if (!h || noutput_items < 0 || (noutput_items > 0 && (!input_items0 || !output_items0))) {
+        doa::set_error("rootMUSIC_linear_array_work: bad arguments");
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (noutput_items == 0) return 0;
+    const size_t in_bytes = (size_t)noutput_items * h->N * h->N * sizeof(float2);
+    const size_t out_bytes = (size_t)noutput_items * h->M * sizeof(float);
+    int rc = h->d_in.reserve(in_bytes);
+    if (rc == DOA_OK) rc = h->d_out.reserve(out_bytes);
+    if (rc == DOA_OK) rc = h->h_status.reserve((size_t)noutput_items * sizeof(int));
+    if (rc != DOA_OK) return rc;
+    DOA_HIP_TRY(hipMemcpyAsync(h->d_in.p, input_items0, in_bytes, hipMemcpyHostToDevice, h->stream));
+    rc = doa_rootMUSIC_linear_array_work_dev(h, noutput_items, h->d_in.p, h->d_out.p, h->stream);
+    if (rc < 0) return rc;
+    DOA_HIP_TRY(hipMemcpyAsync(output_items0, h->d_out.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    DOA_HIP_TRY(hipMemcpyAsync(h->h_status.p, h->d_status.p, (size_t)noutput_items * sizeof(int),
+                               hipMemcpyDeviceToHost, h->stream));
+    DOA_HIP_TRY(hipStreamSynchronize(h->stream));
+    const int *stt = h->h_status.as<int>();
+    for (int i = 0; i < noutput_items; i++)
+        if (stt[i] != 0) {
+            doa::set_error("rootMUSIC_linear_array: item %d has no root strictly inside the unit circle "
+                           "(the reference raises in arma::index_min here)", i);
+            return DOA_ERR_NUMERIC;
+        }
+    return noutput_items;
+}
+
+}  // extern "C"

@@ -1,0 +1,16 @@
+"""`doa` — the hot-path slice of the reference's Python namespace (python/__init__.py:26-41,
+swig/doa_swig.i:22-34), backed by hand-written gfx950 HIP kernels behind a C ABI.
+
+    import doa
+    blk = doa.autocorrelate(inputs, snapshot_size, overlap_size, avg_method)
+    blk = doa.MUSIC_lin_array(norm_spacing, num_targets, inputs, pspectrum_len)
+    blk = doa.find_local_max(num_max_vals, vector_len, x_min, x_max)
+    blk = doa.rootMUSIC_linear_array(norm_spacing, num_targets, inputs)
+
+Importing fails if gr-doa_amd/lib/libdoa_hip.so has not been built; constructing a block fails if
+no HIP device is usable.  There is no CPU fallback.
+"""
+from ._lib import DoaError, LIB_PATH, last_error  # noqa: F401
+from .blocks import (autocorrelate, MUSIC_lin_array, find_local_max, rootMUSIC_linear_array,  # noqa: F401
+                     music_pipeline, set_evd_precision, get_evd_precision, device_count)
+from . import runtime, sim  # noqa: F401

@@ -1,0 +1,97 @@
+"""ctypes binding of libdoa_hip.so (the C ABI declared in include/doa_hip.h).
+
+The library is the product: there is no Python or CPU fallback.  Importing this module fails
+loudly if the shared object has not been built (`make -C gr-doa_amd`), and every block
+constructor raises if no HIP device is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get(
+    "DOA_HIP_LIB", os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libdoa_hip.so")))
+
+
+class DoaError(RuntimeError):
+    """A C-ABI call failed; `.status` is the doa_status code."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libdoa_hip: {message} (status {status})")
+        self.status = status
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build the HIP extension first (make -C gr-doa_amd, or "
+        f"python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+_vp = C.c_void_p
+_vpp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/doa_hip.h one to one
+SIGNATURES = {
+    "doa_last_error": (C.c_char_p, []),
+    "doa_hip_abi_version": (C.c_int, []),
+    "doa_hip_device_count": (C.c_int, []),
+    "doa_set_evd_precision": (C.c_int, [C.c_int]),
+    "doa_get_evd_precision": (C.c_int, []),
+    "doa_autocorrelate_create": (_vp, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "doa_autocorrelate_destroy": (None, [_vp]),
+    "doa_autocorrelate_history": (C.c_int, [_vp]),
+    "doa_autocorrelate_forecast": (C.c_int, [_vp, C.c_int]),
+    "doa_autocorrelate_input_span": (C.c_longlong, [_vp, C.c_int]),
+    "doa_autocorrelate_work": (C.c_int, [_vp, C.c_int, _vpp, _vp]),
+    "doa_autocorrelate_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp]),
+    "doa_MUSIC_lin_array_create": (_vp, [C.c_float, C.c_int, C.c_int, C.c_int]),
+    "doa_MUSIC_lin_array_destroy": (None, [_vp]),
+    "doa_MUSIC_lin_array_work": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "doa_MUSIC_lin_array_work_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "doa_MUSIC_lin_array_debug": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "doa_MUSIC_lin_array_items_total": (C.c_longlong, [_vp]),
+    "doa_find_local_max_create": (_vp, [C.c_int, C.c_int, C.c_float, C.c_float]),
+    "doa_find_local_max_destroy": (None, [_vp]),
+    "doa_find_local_max_work": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "doa_find_local_max_work_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "doa_rootMUSIC_linear_array_create": (_vp, [C.c_float, C.c_int, C.c_int]),
+    "doa_rootMUSIC_linear_array_destroy": (None, [_vp]),
+    "doa_rootMUSIC_linear_array_work": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "doa_rootMUSIC_linear_array_work_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "doa_music_pipeline_create": (_vp, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]),
+    "doa_music_pipeline_destroy": (None, [_vp]),
+    "doa_music_pipeline_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error() -> str:
+    return (lib.doa_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(status: int) -> int:
+    """Raise DoaError for a negative doa_status, pass everything else through."""
+    if status < 0:
+        raise DoaError(status, last_error() or "call failed")
+    return status
+
+
+def check_handle(handle, what: str):
+    if not handle:
+        msg = last_error() or f"{what}: create failed"
+        raise DoaError(-1, msg)
+    return handle
+
+
+def ptr_array(ptrs) -> "C.Array":
+    """Host array of (device or host) pointers, as `const void* const*`."""
+    arr = (C.c_void_p * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = int(p)
+    return arr

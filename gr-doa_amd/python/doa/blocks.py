@@ -1,0 +1,241 @@
+"""Host-side mirror of the reference's `doa` Python namespace for the hot-path blocks.
+
+The reference exposes its C++ blocks to Python through SWIG (`swig/doa_swig.i:22-34`) as
+`doa.autocorrelate(inputs, snapshot_size, overlap_size, avg_method)`,
+`doa.MUSIC_lin_array(norm_spacing, num_targets, inputs, pspectrum_len)`,
+`doa.find_local_max(num_max_vals, vector_len, x_min, x_max)` and
+`doa.rootMUSIC_linear_array(norm_spacing, num_targets, inputs)` — the make strings of the GRC
+descriptors (`grc/doa_*.xml`).  The classes below keep those names and argument orders and forward
+every call to the HIP library through its C ABI (include/doa_hip.h); they hold no arithmetic.
+
+Each block offers
+  * `general_work` / `work(noutput_items, input_items, output_items)` with the item layouts of the
+    GNU Radio buffers (numpy arrays standing in for the scheduler's buffers), used by
+    `doa.runtime`'s mini scheduler, and
+  * `work_dev(...)` on raw device pointers (ints, e.g. `torch.Tensor.data_ptr()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check, check_handle, ptr_array
+
+_C64 = np.complex64
+_F32 = np.float32
+
+
+def _vp(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+def _stream_ptr(stream) -> C.c_void_p:
+    """Accept None, an int (hipStream_t) or a torch.cuda.Stream."""
+    if stream is None:
+        return C.c_void_p(0)
+    if hasattr(stream, "cuda_stream"):
+        return C.c_void_p(int(stream.cuda_stream))
+    return C.c_void_p(int(stream))
+
+
+class _Block:
+    _destroy = None
+
+    def __init__(self):
+        self._h = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            type(self)._destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class autocorrelate(_Block):
+    """doa.autocorrelate(inputs, snapshot_size, overlap_size, avg_method) — gr::block with
+    history overlap_size+1 (reference lib/autocorrelate_impl.cc:47-65)."""
+
+    _destroy = staticmethod(lib.doa_autocorrelate_destroy)
+
+    def __init__(self, inputs, snapshot_size, overlap_size, avg_method):
+        super().__init__()
+        self.inputs, self.snapshot_size = int(inputs), int(snapshot_size)
+        self.overlap_size, self.avg_method = int(overlap_size), int(avg_method)
+        self._h = check_handle(lib.doa_autocorrelate_create(self.inputs, self.snapshot_size,
+                                                            self.overlap_size, self.avg_method),
+                               "autocorrelate")
+        # io signature of the reference block (:49-50)
+        self.in_sig = [(_C64, 1)] * self.inputs
+        self.out_sig = [(_C64, self.inputs * self.inputs)]
+
+    def history(self) -> int:
+        return check(lib.doa_autocorrelate_history(self._h))
+
+    def forecast(self, noutput_items: int) -> int:
+        return check(lib.doa_autocorrelate_forecast(self._h, int(noutput_items)))
+
+    def input_span(self, noutput_items: int) -> int:
+        return int(lib.doa_autocorrelate_input_span(self._h, int(noutput_items)))
+
+    def general_work(self, noutput_items, input_items, output_items):
+        """input_items[k]: complex64 array starting at the first history sample of stream k
+        (at least input_span(noutput_items) long); output_items[0]: [>=n, N*N] complex64.
+        Returns (items produced, items consumed per input) — the caller applies consume_each."""
+        n = int(noutput_items)
+        span = self.input_span(n)
+        arrs = []
+        for k in range(self.inputs):
+            a = np.ascontiguousarray(input_items[k], dtype=_C64)
+            if a.shape[0] < span:
+                raise ValueError(f"input {k}: {a.shape[0]} samples, need {span}")
+            arrs.append(a)
+        out = output_items[0]
+        assert out.dtype == _C64 and out.flags.c_contiguous and out.size >= n * self.inputs ** 2
+        produced = check(lib.doa_autocorrelate_work(self._h, n, ptr_array([a.ctypes.data for a in arrs]),
+                                                    _vp(out)))
+        return produced, self.forecast(produced)
+
+    def work_dev(self, noutput_items, d_input_ptrs, d_out_ptr, stream=None) -> int:
+        return check(lib.doa_autocorrelate_work_dev(self._h, int(noutput_items), ptr_array(d_input_ptrs),
+                                                    C.c_void_p(int(d_out_ptr)), _stream_ptr(stream)))
+
+
+class MUSIC_lin_array(_Block):
+    """doa.MUSIC_lin_array(norm_spacing, num_targets, inputs, pspectrum_len) — gr::sync_block
+    (reference lib/MUSIC_lin_array_impl.cc:47-87)."""
+
+    _destroy = staticmethod(lib.doa_MUSIC_lin_array_destroy)
+
+    def __init__(self, norm_spacing, num_targets, inputs, pspectrum_len):
+        super().__init__()
+        self.norm_spacing, self.num_targets = float(norm_spacing), int(num_targets)
+        self.num_ant_ele, self.pspectrum_len = int(inputs), int(pspectrum_len)
+        self._h = check_handle(lib.doa_MUSIC_lin_array_create(self.norm_spacing, self.num_targets,
+                                                              self.num_ant_ele, self.pspectrum_len),
+                               "MUSIC_lin_array")
+        self.in_sig = [(_C64, self.num_ant_ele ** 2)]
+        self.out_sig = [(_F32, self.pspectrum_len)]
+
+    def work(self, noutput_items, input_items, output_items) -> int:
+        n = int(noutput_items)
+        a = np.ascontiguousarray(input_items[0], dtype=_C64)
+        out = output_items[0]
+        assert a.size >= n * self.num_ant_ele ** 2
+        assert out.dtype == _F32 and out.flags.c_contiguous and out.size >= n * self.pspectrum_len
+        return check(lib.doa_MUSIC_lin_array_work(self._h, n, _vp(a), _vp(out)))
+
+    def work_dev(self, noutput_items, d_in_ptr, d_out_ptr, stream=None) -> int:
+        return check(lib.doa_MUSIC_lin_array_work_dev(self._h, int(noutput_items), C.c_void_p(int(d_in_ptr)),
+                                                      C.c_void_p(int(d_out_ptr)), _stream_ptr(stream)))
+
+    def debug(self, R_items: np.ndarray):
+        """(P_N [n, N*N] complex64 column-major items, Q [n, P] float32) for parity tests."""
+        a = np.ascontiguousarray(R_items, dtype=_C64).reshape(-1, self.num_ant_ele ** 2)
+        n = a.shape[0]
+        pn = np.empty((n, self.num_ant_ele ** 2), dtype=_C64)
+        q = np.empty((n, self.pspectrum_len), dtype=_F32)
+        check(lib.doa_MUSIC_lin_array_debug(self._h, n, _vp(a), _vp(pn), _vp(q)))
+        return pn, q
+
+    def nout_items_total(self) -> int:
+        return int(lib.doa_MUSIC_lin_array_items_total(self._h))
+
+
+class find_local_max(_Block):
+    """doa.find_local_max(num_max_vals, vector_len, x_min, x_max) — gr::sync_block with two
+    outputs (reference lib/find_local_max_impl.cc:47-71)."""
+
+    _destroy = staticmethod(lib.doa_find_local_max_destroy)
+
+    def __init__(self, num_max_vals, vector_len, x_min, x_max):
+        super().__init__()
+        self.num_max_vals, self.vector_len = int(num_max_vals), int(vector_len)
+        self.x_min, self.x_max = float(x_min), float(x_max)
+        self._h = check_handle(lib.doa_find_local_max_create(self.num_max_vals, self.vector_len,
+                                                             self.x_min, self.x_max), "find_local_max")
+        self.in_sig = [(_F32, self.vector_len)]
+        self.out_sig = [(_F32, self.num_max_vals), (_F32, self.num_max_vals)]
+
+    def work(self, noutput_items, input_items, output_items) -> int:
+        n = int(noutput_items)
+        a = np.ascontiguousarray(input_items[0], dtype=_F32)
+        o0, o1 = output_items
+        assert a.size >= n * self.vector_len
+        for o in (o0, o1):
+            assert o.dtype == _F32 and o.flags.c_contiguous and o.size >= n * self.num_max_vals
+        return check(lib.doa_find_local_max_work(self._h, n, _vp(a), _vp(o0), _vp(o1)))
+
+    def work_dev(self, noutput_items, d_in_ptr, d_out0_ptr, d_out1_ptr, stream=None) -> int:
+        return check(lib.doa_find_local_max_work_dev(self._h, int(noutput_items), C.c_void_p(int(d_in_ptr)),
+                                                     C.c_void_p(int(d_out0_ptr)), C.c_void_p(int(d_out1_ptr)),
+                                                     _stream_ptr(stream)))
+
+
+class rootMUSIC_linear_array(_Block):
+    """doa.rootMUSIC_linear_array(norm_spacing, num_targets, inputs) — gr::sync_block
+    (reference lib/rootMUSIC_linear_array_impl.cc:46-59)."""
+
+    _destroy = staticmethod(lib.doa_rootMUSIC_linear_array_destroy)
+
+    def __init__(self, norm_spacing, num_targets, inputs):
+        super().__init__()
+        self.norm_spacing, self.num_targets, self.num_ant_ele = float(norm_spacing), int(num_targets), int(inputs)
+        self._h = check_handle(lib.doa_rootMUSIC_linear_array_create(self.norm_spacing, self.num_targets,
+                                                                     self.num_ant_ele), "rootMUSIC_linear_array")
+        self.in_sig = [(_C64, self.num_ant_ele ** 2)]
+        self.out_sig = [(_F32, self.num_targets)]   # io_signature::make(1, num_targets, ...): port 0 only is written
+
+    def work(self, noutput_items, input_items, output_items) -> int:
+        n = int(noutput_items)
+        a = np.ascontiguousarray(input_items[0], dtype=_C64)
+        out = output_items[0]
+        assert a.size >= n * self.num_ant_ele ** 2
+        assert out.dtype == _F32 and out.flags.c_contiguous and out.size >= n * self.num_targets
+        return check(lib.doa_rootMUSIC_linear_array_work(self._h, n, _vp(a), _vp(out)))
+
+    def work_dev(self, noutput_items, d_in_ptr, d_out_ptr, stream=None) -> int:
+        return check(lib.doa_rootMUSIC_linear_array_work_dev(self._h, int(noutput_items), C.c_void_p(int(d_in_ptr)),
+                                                             C.c_void_p(int(d_out_ptr)), _stream_ptr(stream)))
+
+
+class music_pipeline(_Block):
+    """autocorrelate -> MUSIC_lin_array -> find_local_max(num_targets, pspectrum_len, 0, 180) on
+    device-resident streams (the wiring of apps/run_MUSIC_lin_array_simulation.grc); the batch
+    entry point the benchmark drives.  Not a block of the reference."""
+
+    _destroy = staticmethod(lib.doa_music_pipeline_destroy)
+
+    def __init__(self, inputs, snapshot_size, overlap_size, avg_method, norm_spacing, num_targets,
+                 pspectrum_len, max_batch):
+        super().__init__()
+        self.inputs, self.snapshot_size, self.overlap_size = int(inputs), int(snapshot_size), int(overlap_size)
+        self.avg_method, self.norm_spacing = int(avg_method), float(norm_spacing)
+        self.num_targets, self.pspectrum_len, self.max_batch = int(num_targets), int(pspectrum_len), int(max_batch)
+        self._h = check_handle(lib.doa_music_pipeline_create(self.inputs, self.snapshot_size, self.overlap_size,
+                                                             self.avg_method, self.norm_spacing, self.num_targets,
+                                                             self.pspectrum_len, self.max_batch), "music_pipeline")
+
+    def work_dev(self, noutput_items, d_input_ptrs, d_cov_ptr, d_spec_ptr, d_max_ptr, d_argmax_ptr, stream=None) -> int:
+        return check(lib.doa_music_pipeline_work_dev(
+            self._h, int(noutput_items), ptr_array(d_input_ptrs), C.c_void_p(int(d_cov_ptr or 0)),
+            C.c_void_p(int(d_spec_ptr or 0)), C.c_void_p(int(d_max_ptr)), C.c_void_p(int(d_argmax_ptr)),
+            _stream_ptr(stream)))
+
+
+def set_evd_precision(bits: int) -> None:
+    check(lib.doa_set_evd_precision(int(bits)))
+
+
+def get_evd_precision() -> int:
+    return int(lib.doa_get_evd_precision())
+
+
+def device_count() -> int:
+    return int(lib.doa_hip_device_count())

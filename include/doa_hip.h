@@ -1,0 +1,192 @@
+/*
+ * doa_hip.h — C ABI of libdoa_hip.so, the MI355X (gfx950) implementation of gr-doa's hot path
+ *
+ *     autocorrelate -> MUSIC_lin_array (+ find_local_max)  /  rootMUSIC_linear_array
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Every block of the
+ * reference that sits on the path gets one opaque handle type with
+ *
+ *     doa_X_create(<the reference's make() arguments>)   -> handle, or NULL + doa_last_error()
+ *     doa_X_work(h, noutput_items, <host pointers laid out like the GNU Radio item buffers>)
+ *     doa_X_work_dev(h, noutput_items, <device pointers, same layouts>, hipStream_t as void*)
+ *     doa_X_destroy(h)
+ *
+ * `work` returns the number of items produced (what the reference's work()/general_work()
+ * returns) or a negative doa_status on failure; it never falls back to a CPU path: if no HIP
+ * device / kernel is usable the call fails and doa_last_error() says why.
+ *
+ * Reference interfaces replaced (paths relative to the gr-doa tree):
+ *   doa_autocorrelate_*          include/doa/autocorrelate.h:56, lib/autocorrelate_impl.cc:47-118
+ *   doa_MUSIC_lin_array_*        include/doa/MUSIC_lin_array.h:56, lib/MUSIC_lin_array_impl.cc:47-150
+ *   doa_find_local_max_*         include/doa/find_local_max.h:56, lib/find_local_max_impl.cc:47-194
+ *   doa_rootMUSIC_linear_array_* include/doa/rootMUSIC_linear_array.h:54,
+ *                                lib/rootMUSIC_linear_array_impl.cc:46-152
+ *   doa_music_pipeline_*         the three blocks as wired by apps/run_MUSIC_lin_array_simulation.grc
+ *                                (autocorrelate -> MUSIC_lin_array -> find_local_max(M, P, 0, 180))
+ *
+ * Threading: like GNU Radio's thread-per-block scheduler assumes, different handles may be used
+ * from different threads concurrently; one handle must not be used from two threads at once.
+ * Ownership: the caller owns every buffer it passes; the library owns its device tables, staging
+ * buffers and (for the host-pointer entry points) one HIP stream per handle.
+ */
+#ifndef DOA_HIP_H
+#define DOA_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define DOA_HIP_API __attribute__((visibility("default")))
+#else
+#define DOA_HIP_API
+#endif
+
+typedef enum doa_status {
+    DOA_OK = 0,
+    DOA_ERR_INVALID_ARG = -1, /* a constructor/work argument violates the block's contract        */
+    DOA_ERR_NO_DEVICE = -2,   /* no HIP device (or the HIP runtime failed to initialise)         */
+    DOA_ERR_HIP = -3,         /* a HIP runtime call or kernel launch failed                      */
+    DOA_ERR_UNSUPPORTED = -4, /* valid for the reference, not built into this library (size caps) */
+    DOA_ERR_NUMERIC = -5      /* the reference would raise here (e.g. no root inside the circle)  */
+} doa_status;
+
+/* Largest array the HIP kernels are instantiated for (the reference's flowgraphs use 4, its QA
+ * tests 4/8/16). */
+#define DOA_MAX_ANT_ELE 16
+/* Largest num_max_vals / num_targets handled by the peak-pick kernel. */
+#define DOA_MAX_PEAKS 16
+
+/* Thread-local description of the last failure on the calling thread ("" if none). */
+DOA_HIP_API const char *doa_last_error(void);
+/* Library/ABI version, bumped when a signature changes. */
+DOA_HIP_API int doa_hip_abi_version(void);
+/* Number of visible HIP devices (0 if none / runtime unusable). Does not create a context. */
+DOA_HIP_API int doa_hip_device_count(void);
+
+/* Precision of the batched Hermitian eigendecomposition used by MUSIC / Root-MUSIC handles
+ * created *after* the call: 32 = float Jacobi, 64 = double Jacobi (default).  Inputs and outputs
+ * stay complex64 / float32 either way.  Returns DOA_OK or DOA_ERR_INVALID_ARG. */
+DOA_HIP_API int doa_set_evd_precision(int bits);
+DOA_HIP_API int doa_get_evd_precision(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * autocorrelate — gr::doa::autocorrelate::make(inputs, snapshot_size, overlap_size, avg_method)
+ *   (include/doa/autocorrelate.h:56).  gr::block with history overlap_size+1
+ *   (lib/autocorrelate_impl.cc:57) and forecast nonoverlap*noutput (:75-80).
+ * Item layouts: input_items[k] = stream k, gr_complex (float re, im), pointing at the first
+ *   history sample exactly like general_work's input_items[k]; window i is the snapshot_size
+ *   samples starting at input_items[k] + i*(snapshot_size-overlap_size) (:95-100).
+ *   output = noutput_items column-major inputs x inputs gr_complex matrices (:103).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct doa_autocorrelate doa_autocorrelate_t;
+
+DOA_HIP_API doa_autocorrelate_t *doa_autocorrelate_create(int inputs, int snapshot_size,
+                                                          int overlap_size, int avg_method);
+DOA_HIP_API void doa_autocorrelate_destroy(doa_autocorrelate_t *h);
+/* set_history() value the shell must apply: overlap_size + 1. */
+DOA_HIP_API int doa_autocorrelate_history(const doa_autocorrelate_t *h);
+/* forecast(): new input items required per stream for noutput_items outputs. */
+DOA_HIP_API int doa_autocorrelate_forecast(const doa_autocorrelate_t *h, int noutput_items);
+/* Samples per stream that must be readable behind input_items[k]:
+ * (noutput_items-1)*(snapshot-overlap) + snapshot. */
+DOA_HIP_API long long doa_autocorrelate_input_span(const doa_autocorrelate_t *h, int noutput_items);
+/* general_work on host buffers; the shell then calls consume_each(forecast(noutput_items)). */
+DOA_HIP_API int doa_autocorrelate_work(doa_autocorrelate_t *h, int noutput_items,
+                                       const void *const *input_items, void *output_items0);
+/* Same on device buffers: d_input_items is a HOST array of `inputs` DEVICE pointers. Asynchronous
+ * on `hip_stream` (a hipStream_t, NULL = the default stream). */
+DOA_HIP_API int doa_autocorrelate_work_dev(doa_autocorrelate_t *h, int noutput_items,
+                                           const void *const *d_input_items, void *d_output_items0,
+                                           void *hip_stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MUSIC_lin_array — gr::doa::MUSIC_lin_array::make(norm_spacing, num_targets, num_ant_ele,
+ *   pspectrum_len) (include/doa/MUSIC_lin_array.h:56).  gr::sync_block.
+ * Item layouts: input = column-major num_ant_ele^2 gr_complex (only the upper triangle is
+ *   significant, as with LAPACK uplo='U'); output = pspectrum_len floats, dB normalised to the
+ *   item's maximum (lib/MUSIC_lin_array_impl.cc:49-50,124-142).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct doa_MUSIC_lin_array doa_MUSIC_lin_array_t;
+
+DOA_HIP_API doa_MUSIC_lin_array_t *doa_MUSIC_lin_array_create(float norm_spacing, int num_targets,
+                                                              int num_ant_ele, int pspectrum_len);
+DOA_HIP_API void doa_MUSIC_lin_array_destroy(doa_MUSIC_lin_array_t *h);
+DOA_HIP_API int doa_MUSIC_lin_array_work(doa_MUSIC_lin_array_t *h, int noutput_items,
+                                         const void *input_items0, void *output_items0);
+DOA_HIP_API int doa_MUSIC_lin_array_work_dev(doa_MUSIC_lin_array_t *h, int noutput_items,
+                                             const void *d_input_items0, void *d_output_items0,
+                                             void *hip_stream);
+/* Diagnostics used by the parity tests (host buffers, synchronous): the noise-subspace projector
+ * U_N U_N^H of each item (column-major num_ant_ele^2 gr_complex, lib/MUSIC_lin_array_impl.cc:133)
+ * and the un-normalised null spectrum Q_i = Re(a_i^H P_N a_i) (:139), pspectrum_len floats per
+ * item.  Either output pointer may be NULL. */
+DOA_HIP_API int doa_MUSIC_lin_array_debug(doa_MUSIC_lin_array_t *h, int noutput_items,
+                                          const void *input_items0, void *projector_out,
+                                          void *null_spectrum_out);
+/* Items processed so far — the counter the reference prints from its destructor
+ * (lib/MUSIC_lin_array_impl.cc:92-95,146). */
+DOA_HIP_API long long doa_MUSIC_lin_array_items_total(const doa_MUSIC_lin_array_t *h);
+
+/* ---------------------------------------------------------------------------------------------
+ * find_local_max — gr::doa::find_local_max::make(num_max_vals, vector_len, x_min, x_max)
+ *   (include/doa/find_local_max.h:56).  gr::sync_block with two outputs.
+ * Item layouts: input = vector_len floats; output 0 = num_max_vals floats (peak values, descending
+ *   value order); output 1 = num_max_vals floats (x-axis locations of those peaks, sorted
+ *   descending on their own) (lib/find_local_max_impl.cc:49-50,186-188).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct doa_find_local_max doa_find_local_max_t;
+
+DOA_HIP_API doa_find_local_max_t *doa_find_local_max_create(int num_max_vals, int vector_len,
+                                                            float x_min, float x_max);
+DOA_HIP_API void doa_find_local_max_destroy(doa_find_local_max_t *h);
+DOA_HIP_API int doa_find_local_max_work(doa_find_local_max_t *h, int noutput_items,
+                                        const void *input_items0, void *output_items0,
+                                        void *output_items1);
+DOA_HIP_API int doa_find_local_max_work_dev(doa_find_local_max_t *h, int noutput_items,
+                                            const void *d_input_items0, void *d_output_items0,
+                                            void *d_output_items1, void *hip_stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * rootMUSIC_linear_array — gr::doa::rootMUSIC_linear_array::make(norm_spacing, num_targets,
+ *   num_ant_ele) (include/doa/rootMUSIC_linear_array.h:54).  gr::sync_block.
+ * Item layouts: input as MUSIC_lin_array; output 0 = num_targets floats, angles in degrees,
+ *   ascending (lib/rootMUSIC_linear_array_impl.cc:48-49,144-145).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct doa_rootMUSIC_linear_array doa_rootMUSIC_linear_array_t;
+
+DOA_HIP_API doa_rootMUSIC_linear_array_t *doa_rootMUSIC_linear_array_create(float norm_spacing,
+                                                                            int num_targets,
+                                                                            int num_ant_ele);
+DOA_HIP_API void doa_rootMUSIC_linear_array_destroy(doa_rootMUSIC_linear_array_t *h);
+DOA_HIP_API int doa_rootMUSIC_linear_array_work(doa_rootMUSIC_linear_array_t *h, int noutput_items,
+                                                const void *input_items0, void *output_items0);
+DOA_HIP_API int doa_rootMUSIC_linear_array_work_dev(doa_rootMUSIC_linear_array_t *h,
+                                                    int noutput_items, const void *d_input_items0,
+                                                    void *d_output_items0, void *hip_stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * music_pipeline — autocorrelate -> MUSIC_lin_array -> find_local_max(num_targets, pspectrum_len,
+ *   0, 180) on device-resident streams, the batch entry point the benchmark drives
+ *   (apps/run_MUSIC_lin_array_simulation.grc wiring).  All pointers are DEVICE pointers except
+ *   d_input_items itself (host array of device pointers).  d_cov_out and d_spectrum_out may be
+ *   NULL when the caller does not want that intermediate materialised in its own buffer.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct doa_music_pipeline doa_music_pipeline_t;
+
+DOA_HIP_API doa_music_pipeline_t *doa_music_pipeline_create(int inputs, int snapshot_size,
+                                                            int overlap_size, int avg_method,
+                                                            float norm_spacing, int num_targets,
+                                                            int pspectrum_len, int max_batch);
+DOA_HIP_API void doa_music_pipeline_destroy(doa_music_pipeline_t *h);
+DOA_HIP_API int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput_items,
+                                            const void *const *d_input_items, void *d_cov_out,
+                                            void *d_spectrum_out, void *d_max_out,
+                                            void *d_argmax_out, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOA_HIP_H */

@@ -1,0 +1,368 @@
+"""CPU oracle for the gr-doa hot path (TEST INFRASTRUCTURE — never imported by the product).
+
+    autocorrelate -> MUSIC_lin_array (+ find_local_max) / rootMUSIC_linear_array
+
+This is a numpy/scipy restatement of the reference's Armadillo arithmetic, one function per
+reference routine, each citing the reference file:line it follows (paths relative to the
+read-only reference tree).  Armadillo itself only forwards to BLAS/LAPACK for the heavy steps
+(`cgemm`, `cheevd`, `cgeev`), so the fp32 path below calls those *same* LAPACK routines through
+scipy's bundled OpenBLAS (`scipy.linalg.lapack.cheevd/cgeev`) and keeps every intermediate in the
+type the reference keeps it in (complex64 / float32, with the few double-precision scalar
+sub-expressions the C++ promotes).
+
+PARITY STATUS: **parity unpinned** with respect to the reference's own outputs.  The reference
+stores no golden vectors (its QA tests mint inputs and expectations at run time through Octave,
+`python/qa_*.py`), and neither Armadillo, GNU Radio nor Octave exist in the build image, so the
+reference could not be run.  What pins this oracle instead (tests/test_oracle_*.py):
+  * the reference's own deterministic QA scenario for find_local_max
+    (`python/test001_findpeaks.m`, `python/test002_findpeaks.m`) checked against an independent
+    peak finder (`scipy.signal.find_peaks`) to the reference's 5-decimal tolerance;
+  * the reference's QA scenarios and tolerances for autocorrelate / MUSIC / Root-MUSIC
+    (|dR| <= 1.0, |d angle| <= 2.0 deg: `python/qa_autocorrelate.py:82`,
+    `python/qa_MUSIC_lin_array.py:96`, `python/qa_rootMUSIC_linear_array.py:87`) on seeded inputs;
+  * an fp64 evaluation (`precision="f64"`: zheevd/zgeev, double tables) of the same formulas.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import this file.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+try:  # scipy is part of the image; keep the import local to the functions that need LAPACK
+    from scipy.linalg import lapack as _lapack
+except Exception:  # pragma: no cover
+    _lapack = None
+
+_F32 = np.float32
+_C64 = np.complex64
+
+
+# --------------------------------------------------------------------------------------------
+# autocorrelate  (lib/autocorrelate_impl.cc)
+# --------------------------------------------------------------------------------------------
+def gr_history_prepend(streams: np.ndarray, overlap_size: int) -> np.ndarray:
+    """GNU Radio `set_history(overlap+1)` view of a stream start.
+
+    lib/autocorrelate_impl.cc:57 — the scheduler hands `input_items[k]` pointing `overlap`
+    samples *before* the first new sample and the history is zero-filled at stream start, so
+    snapshot 0 begins with `overlap` zeros.  streams: [N, T] complex64 -> [N, overlap+T].
+    """
+    streams = np.asarray(streams, dtype=_C64)
+    pad = np.zeros((streams.shape[0], overlap_size), dtype=_C64)
+    return np.concatenate([pad, streams], axis=1)
+
+
+def autocorrelate_noutput(n_samples_with_history: int, snapshot_size: int, overlap_size: int) -> int:
+    """Number of whole windows in a buffer of `n_samples_with_history` samples per stream.
+
+    lib/autocorrelate_impl.cc:75-80 (forecast): each output needs `snapshot-overlap` new items;
+    window i spans [i*nonoverlap, i*nonoverlap + snapshot).
+    """
+    nonoverlap = snapshot_size - overlap_size
+    if n_samples_with_history < snapshot_size:
+        return 0
+    return (n_samples_with_history - snapshot_size) // nonoverlap + 1
+
+
+def autocorrelate(input_items: np.ndarray, snapshot_size: int, overlap_size: int,
+                  avg_method: int, output_matrices: int | None = None,
+                  precision: str = "f32") -> np.ndarray:
+    """general_work of doa::autocorrelate.  lib/autocorrelate_impl.cc:83-118.
+
+    input_items: [N, >= (n-1)*(K-ovl)+K] complex64, *including* the history samples (window i
+    starts at sample i*(K-ovl), exactly `input_items[k] + i*d_nonoverlap_size`, :98).
+    Returns [n, N*N] complex64; each item is the column-major N x N matrix the block writes
+    (:103), R[a,b] = (1/K) sum_t x_a[t] conj(x_b[t]) (:106), optionally followed by
+    R <- 0.5 R + (0.5/K) J conj(R) J (:107-108; note the second term is divided by K again —
+    reproduced as written, also in examples/@wpi_twinrx_doa_testbench/autocorrelate.m:42-44).
+    """
+    x = np.asarray(input_items, dtype=_C64)
+    n_in, total = x.shape
+    K = int(snapshot_size)
+    S = K - int(overlap_size)
+    if output_matrices is None:
+        output_matrices = autocorrelate_noutput(total, K, overlap_size)
+    out = np.empty((output_matrices, n_in * n_in), dtype=_C64)
+    J = np.fliplr(np.eye(n_in))                                   # :61-62
+    cdt, rdt = (_C64, _F32) if precision == "f32" else (np.complex128, np.float64)
+    for i in range(output_matrices):
+        X = x[:, i * S:i * S + K].T.astype(cdt)                   # K x N, :95-100
+        if X.shape[0] != K:
+            raise ValueError("input shorter than the windows requested")
+        # (1.0/K) * X.st() * conj(X): Armadillo folds the scalar into cgemm's alpha (as eT).
+        R = (rdt(1.0 / K) * (X.T @ np.conj(X))).astype(cdt)       # :106
+        if avg_method == 1:
+            JRJ = (J.astype(cdt) @ np.conj(R) @ J.astype(cdt)).astype(cdt)
+            R = (rdt(0.5) * R + rdt(0.5 / K) * JRJ).astype(cdt)   # :107-108
+        out[i] = R.astype(_C64).reshape(-1, order="F")            # column-major, :103
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# MUSIC_lin_array  (lib/MUSIC_lin_array_impl.cc)
+# --------------------------------------------------------------------------------------------
+def music_array_loc(norm_spacing: float, num_ant_ele: int) -> np.ndarray:
+    """lib/MUSIC_lin_array_impl.cc:57-61: float(norm_spacing)*0.5*(N-1-2n), double expr -> float."""
+    d = float(_F32(norm_spacing))
+    return np.array([d * 0.5 * (num_ant_ele - 1 - 2 * nn) for nn in range(num_ant_ele)], dtype=_F32)
+
+
+def music_theta_grid(pspectrum_len: int) -> np.ndarray:
+    """lib/MUSIC_lin_array_impl.cc:64-72: float accumulator theta += 180.0/P (sum in double,
+    stored to float each step), d_theta[i] = float(pi*theta/180.0)."""
+    theta = np.zeros(pspectrum_len, dtype=_F32)
+    theta_prev = _F32(0.0)
+    step = 180.0 / pspectrum_len
+    for ii in range(1, pspectrum_len):
+        t = _F32(float(theta_prev) + step)
+        theta_prev = t
+        theta[ii] = _F32(np.pi * float(t) / 180.0)
+    return theta
+
+
+def music_steering(norm_spacing: float, num_ant_ele: int, pspectrum_len: int,
+                   precision: str = "f32") -> np.ndarray:
+    """Steering table d_vii_matrix (N x P).  lib/MUSIC_lin_array_impl.cc:75-86,98-104.
+
+    amv: v = exp(i * ((-1.0*2*pi*cos(theta)) * array_loc)); the scalar is a double expression
+    that Armadillo casts to float when it scales the fcolvec, the product scalar*loc is a float
+    multiply, and exp is std::exp(complex<float>) = (cosf(y), sinf(y)) for a zero real part.
+    precision="f64" evaluates the same grid/locations (which are *defined* in float) with double
+    phases and double exp — the reference's formula without its float rounding.
+    """
+    loc = music_array_loc(norm_spacing, num_ant_ele)
+    theta = music_theta_grid(pspectrum_len)
+    if precision == "f32":
+        k = (-1.0 * 2 * np.pi * np.cos(theta.astype(np.float64))).astype(_F32)   # scalar -> float
+        phase = (k[None, :] * loc[:, None]).astype(_F32)                          # float multiply
+        return (np.cos(phase) + 1j * np.sin(phase)).astype(_C64)
+    k = -1.0 * 2 * np.pi * np.cos(theta.astype(np.float64))
+    phase = k[None, :] * loc.astype(np.float64)[:, None]
+    return np.cos(phase) + 1j * np.sin(phase)
+
+
+def _eig_sym(R: np.ndarray, precision: str):
+    """arma::eig_sym (default "dc") = LAPACK ?heevd(jobz='V', uplo='U'), ascending eigenvalues;
+    only the upper triangle is referenced.  lib/MUSIC_lin_array_impl.cc:128."""
+    if precision == "f32":
+        w, v, info = _lapack.cheevd(np.asarray(R, dtype=_C64), compute_v=1, lower=0)
+    else:
+        w, v, info = _lapack.zheevd(np.asarray(R, dtype=np.complex128), compute_v=1, lower=0)
+    if info != 0:
+        raise np.linalg.LinAlgError(f"heevd info={info}")
+    return w, v
+
+
+def noise_projector(R_item: np.ndarray, num_targets: int, num_ant_ele: int,
+                    precision: str = "f32") -> np.ndarray:
+    """U_N U_N^H with U_N = the N-M eigenvectors of the smallest eigenvalues.
+    lib/MUSIC_lin_array_impl.cc:124-133 (identically lib/rootMUSIC_linear_array_impl.cc:108-116)."""
+    N = num_ant_ele
+    R = np.asarray(R_item).reshape(N, N, order="F")               # column-major item, :124
+    _, V = _eig_sym(R, precision)
+    U_N = V[:, :N - num_targets]                                  # :131
+    return U_N @ U_N.conj().T                                     # :133
+
+
+def music_null_spectrum(P_N: np.ndarray, A: np.ndarray) -> np.ndarray:
+    """Q_i = Re( a_i^H P_N a_i ), evaluated as (row * P_N) * col like Armadillo's 3-operand
+    product for a 1xN * NxN * Nx1 chain.  lib/MUSIC_lin_array_impl.cc:137-139."""
+    T = A.conj().T @ P_N                                          # P x N   (d_vii_matrix_trans rows)
+    Q = np.einsum("in,ni->i", T, A)
+    return Q.real
+
+
+def music_lin_array(R_items: np.ndarray, norm_spacing: float, num_targets: int, num_ant_ele: int,
+                    pspectrum_len: int, precision: str = "f32", return_parts: bool = False):
+    """work() of doa::MUSIC_lin_array.  lib/MUSIC_lin_array_impl.cc:108-150.
+
+    R_items: [n, N*N] complex64 (column-major items).  Returns [n, P] float32 dB spectrum,
+    10*log10(out/max(out)) with out = 1/Re(Q) (:140-142).  With return_parts also returns the
+    per-item null spectrum Q and projector P_N (the quantities parity is graded on).
+    """
+    R_items = np.asarray(R_items)
+    n = R_items.shape[0]
+    N, P = num_ant_ele, pspectrum_len
+    A = music_steering(norm_spacing, N, P, precision)
+    rdt = _F32 if precision == "f32" else np.float64
+    spec = np.empty((n, P), dtype=rdt)
+    Qs = np.empty((n, P), dtype=rdt)
+    PNs = np.empty((n, N, N), dtype=_C64 if precision == "f32" else np.complex128)
+    for item in range(n):
+        P_N = noise_projector(R_items[item], num_targets, N, precision)
+        Q = music_null_spectrum(P_N, A).astype(rdt)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            out = (1.0 / Q.astype(np.float64)).astype(rdt)        # 1.0/Q_temp.real(): double divide -> float
+            out = (out / out.max()).astype(rdt)
+            spec[item] = (rdt(10.0) * np.log10(out)).astype(rdt)  # :142
+        Qs[item] = Q
+        PNs[item] = P_N
+    if return_parts:
+        return spec, Qs, PNs
+    return spec
+
+
+# --------------------------------------------------------------------------------------------
+# find_local_max  (lib/find_local_max_impl.cc, lib/find_local_max_impl.h)
+# --------------------------------------------------------------------------------------------
+def find_local_max_x_axis(vector_len: int, x_min: float, x_max: float) -> np.ndarray:
+    """lib/find_local_max_impl.cc:60-69: float accumulation x += (x_max-x_min)/L, all in float."""
+    x = np.empty(vector_len, dtype=_F32)
+    x[0] = _F32(x_min)
+    x_prev = _F32(x_min)
+    step = _F32(_F32(_F32(x_max) - _F32(x_min)) / _F32(vector_len))
+    for ii in range(1, vector_len):
+        x_prev = _F32(x_prev + step)
+        x[ii] = x_prev
+    return x
+
+
+def _index_max(v: np.ndarray) -> int:
+    """arma index_max (op_max::direct_max): best starts at -inf and is replaced only by a strictly
+    greater element -> first occurrence of the maximum; NaNs never win; nothing > -inf -> 0."""
+    ok = v > -np.inf                      # False for NaN and -inf
+    if not ok.any():
+        return 0
+    return int(np.argmax(np.where(ok, v, -np.inf)))
+
+
+def _peak_indices_one(v: np.ndarray) -> np.ndarray:
+    """find_one_local_peak_indx: index_max (first occurrence).  lib/find_local_max_impl.h:53-56."""
+    return np.array([_index_max(v)], dtype=np.int64)
+
+
+def _peak_indices_many(v: np.ndarray, num_max_vals: int) -> np.ndarray:
+    """find_more_than_one_local_peak_indxs.  lib/find_local_max_impl.cc:80-165."""
+    L = v.shape[0]
+    s = np.sign(np.diff(v)).astype(_F32)                          # :89
+    flats = np.nonzero(s == 0)[0]                                 # :92
+    for idx in flats[::-1]:                                       # :94-107, right to left, in place
+        nxt = min(int(idx) + 1, s.shape[0] - 1)
+        s[idx] = 1.0 if s[nxt] >= 0 else -1.0
+    all_pk = np.nonzero(np.diff(s) == -2)[0] + 1                  # :114
+    all_pks = v[all_pk]
+    # sort_index(all_pks, "descend") (:137) — Armadillo's non-stable sort; ties are ordered by
+    # position here (lowest index first), the one documented deviation (tie order is unspecified
+    # in the reference).
+    order = np.argsort(-all_pks.astype(np.float64), kind="stable")
+    n_valid = order.shape[0]
+    pk = np.empty(num_max_vals, dtype=np.int64)
+    if n_valid >= num_max_vals:                                   # :141-144
+        pk[:] = all_pk[order[:num_max_vals]]
+    else:                                                         # :145-163
+        if n_valid == 0:
+            fill = _index_max(v)                                  # global arg-max
+        else:
+            # NOTE (reproduced quirk): the reference assigns `all_pks_sorted_indx(0)` — the
+            # position of the best peak *inside the peak list*, not its index in the input
+            # vector — and uses that number as the fill index (:153,160).
+            fill = int(order[0])
+        for ind in range(num_max_vals):
+            pk[ind] = all_pk[order[ind]] if ind < n_valid else fill
+    return pk
+
+
+def find_local_max(in_items: np.ndarray, num_max_vals: int, vector_len: int,
+                   x_min: float, x_max: float):
+    """work() of doa::find_local_max.  lib/find_local_max_impl.cc:167-194.
+
+    Returns (max_vals [n, M], arg_max [n, M]); port 0 = in_vec(pk_indxs) in descending-value
+    order, port 1 = sort(x_axis(pk_indxs), "descend") — the two ports are sorted independently
+    (:186-188).
+    """
+    v_all = np.asarray(in_items, dtype=_F32).reshape(-1, vector_len)
+    x_axis = find_local_max_x_axis(vector_len, x_min, x_max)
+    n = v_all.shape[0]
+    vals = np.empty((n, num_max_vals), dtype=_F32)
+    locs = np.empty((n, num_max_vals), dtype=_F32)
+    for item in range(n):
+        v = v_all[item]
+        pk = _peak_indices_one(v) if num_max_vals == 1 else _peak_indices_many(v, num_max_vals)
+        vals[item] = v[pk]
+        locs[item] = np.sort(x_axis[pk])[::-1]
+    return vals, locs
+
+
+# --------------------------------------------------------------------------------------------
+# rootMUSIC_linear_array  (lib/rootMUSIC_linear_array_impl.cc)
+# --------------------------------------------------------------------------------------------
+def root_music_polynomial(P_N: np.ndarray) -> np.ndarray:
+    """get_roots_polynomial, coefficient part.  lib/rootMUSIC_linear_array_impl.cc:68-80.
+    u[ii+N-1] = sum(diag(P_N, ii)) for sub-diagonals ii<0, mirrored conjugates above, trace in
+    the middle; then u <- (-1/u[2N-2]) u."""
+    N = P_N.shape[0]
+    u = np.zeros(2 * N - 1, dtype=P_N.dtype)
+    for ii in range(-N + 1, 0):
+        u[ii + N - 1] = np.sum(np.diagonal(P_N, offset=ii))
+        u[N - 1 - ii] = np.conj(u[ii + N - 1])
+    u[N - 1] = np.sum(np.diagonal(P_N))
+    u = (P_N.dtype.type(-1.0) / u[2 * N - 2]) * u
+    return u.astype(P_N.dtype)
+
+
+def root_music_roots(P_N: np.ndarray, precision: str = "f32") -> np.ndarray:
+    """Companion matrix (ones on the first sub-diagonal, last column = u[0..2N-3]) and its
+    eigenvalues via eig_gen = LAPACK ?geev without vectors.
+    lib/rootMUSIC_linear_array_impl.cc:55-58,82-86."""
+    N = P_N.shape[0]
+    n = 2 * N - 2
+    u = root_music_polynomial(P_N)
+    C = np.zeros((n, n), dtype=P_N.dtype)
+    C[np.arange(1, n), np.arange(0, n - 1)] = 1.0
+    C[:, n - 1] = u[:n]
+    if precision == "f32":
+        w, _, _, info = _lapack.cgeev(C.astype(_C64), compute_vl=0, compute_vr=0)
+    else:
+        w, _, _, info = _lapack.zgeev(C.astype(np.complex128), compute_vl=0, compute_vr=0)
+    if info != 0:
+        raise np.linalg.LinAlgError(f"geev info={info}")
+    return w
+
+
+def root_music(R_items: np.ndarray, norm_spacing: float, num_targets: int, num_ant_ele: int,
+               precision: str = "f32") -> np.ndarray:
+    """work() of doa::rootMUSIC_linear_array.  lib/rootMUSIC_linear_array_impl.cc:90-152.
+    Returns [n, M] float32 angles in degrees, ascending."""
+    R_items = np.asarray(R_items)
+    n = R_items.shape[0]
+    N, M = num_ant_ele, num_targets
+    d = float(_F32(norm_spacing))
+    rdt = _F32 if precision == "f32" else np.float64
+    out = np.empty((n, M), dtype=_F32)
+    for item in range(n):
+        P_N = noise_projector(R_items[item], M, N, precision)
+        roots = root_music_roots(P_N, precision)
+        dist = (rdt(1.0) - np.abs(roots)).astype(rdt)             # :122
+        inside = np.nonzero(dist > 0.0)[0]                        # :125
+        roots_in = roots[inside].copy()
+        dist_in = dist[inside].copy()
+        aoa = np.empty(M, dtype=_F32)
+        for ii in range(M):                                       # :131-141
+            if dist_in.shape[0] == 0:
+                raise ValueError("no root strictly inside the unit circle (Armadillo index_min error)")
+            k = int(np.argmin(dist_in))
+            z = roots_in[k]
+            if np.isinf(z.real):
+                ang = rdt(0.0)                                    # arg(inf+0i) = 0 -> 90 deg
+            else:
+                ang = rdt(np.angle(z))                            # std::arg in the root's type
+            with np.errstate(invalid="ignore"):
+                aoa[ii] = _F32(180.0 * np.arccos(float(ang) / (2 * np.pi * d)) / np.pi)
+            dist_in[k] = np.inf
+            roots_in[k] = complex(np.inf, 0.0)
+        out[item] = np.sort(aoa)                                  # :144
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# whole path, as the flowgraph wires it (apps/run_MUSIC_lin_array_simulation.grc)
+# --------------------------------------------------------------------------------------------
+def music_pipeline(input_items: np.ndarray, snapshot_size: int, overlap_size: int, avg_method: int,
+                   norm_spacing: float, num_targets: int, pspectrum_len: int,
+                   output_matrices: int | None = None, precision: str = "f32"):
+    """autocorrelate -> MUSIC_lin_array -> find_local_max(M, P, 0, 180)."""
+    N = np.asarray(input_items).shape[0]
+    R = autocorrelate(input_items, snapshot_size, overlap_size, avg_method, output_matrices)
+    spec = music_lin_array(R, norm_spacing, num_targets, N, pspectrum_len, precision)
+    vals, locs = find_local_max(spec.astype(_F32), num_targets, pspectrum_len, 0.0, 180.0)
+    return R, spec, vals, locs

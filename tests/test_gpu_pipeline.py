@@ -1,0 +1,78 @@
+"""GPU tests of the device-resident pipeline (doa.music_pipeline = autocorrelate -> MUSIC_lin_array
+-> find_local_max on device pointers), the entry point bench.py drives."""
+import numpy as np
+import pytest
+
+import doa
+import doa_oracle as oracle
+from scenarios import make_input
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("name", ["bench_cfg2", "grc_music_sim", "three_ant_fb", "qa_music_aoa23", "five_ant"])
+def test_pipeline_equals_chained_blocks_and_oracle(name):
+    c, x = make_input(name)
+    N, M, P, n = c["N"], c["M"], c["P"], c["n"]
+    streams = [_dev(x[k]) for k in range(N)]
+    cov = torch.empty((n, N * N), dtype=torch.complex64, device="cuda")
+    spec = torch.empty((n, P), dtype=torch.float32, device="cuda")
+    mx = torch.empty((n, M), dtype=torch.float32, device="cuda")
+    am = torch.empty((n, M), dtype=torch.float32, device="cuda")
+    pipe = doa.music_pipeline(N, c["K"], c["ovl"], c["fb"], c["d"], M, P, max_batch=n)
+    st = torch.cuda.current_stream()
+    assert pipe.work_dev(n, [s.data_ptr() for s in streams], cov.data_ptr(), spec.data_ptr(), mx.data_ptr(),
+                         am.data_ptr(), st) == n
+    torch.cuda.synchronize()
+    # the same through the three block objects on host buffers
+    a = doa.autocorrelate(N, c["K"], c["ovl"], c["fb"])
+    R = np.empty((n, N * N), np.complex64)
+    a.general_work(n, [x[k] for k in range(N)], [R])
+    m = doa.MUSIC_lin_array(c["d"], M, N, P)
+    S = np.empty((n, P), np.float32)
+    m.work(n, [R], [S])
+    f = doa.find_local_max(M, P, 0.0, 180.0)
+    v0 = np.empty((n, M), np.float32)
+    v1 = np.empty((n, M), np.float32)
+    f.work(n, [S], [v0, v1])
+    assert np.array_equal(cov.cpu().numpy(), R)
+    assert np.array_equal(spec.cpu().numpy(), S)
+    assert np.array_equal(mx.cpu().numpy(), v0) and np.array_equal(am.cpu().numpy(), v1)
+    # and against the oracle: covariance to rounding, angles on the grid
+    R64 = oracle.autocorrelate(x, c["K"], c["ovl"], c["fb"], n, precision="f64")
+    assert np.abs(R - R64).max() <= 2e-6 * np.abs(R64).max()
+    _, _, _, loc = oracle.music_pipeline(x, c["K"], c["ovl"], c["fb"], c["d"], M, P, n)
+    assert np.abs(v1 - loc).max() <= 180.0 / P + 1e-3
+
+
+def test_pipeline_full_batch_recovers_directions():
+    """BASELINE.json configs[1] at full size (N=4, K=1024, P=1024, batch 4096, SNR 20 dB): the
+    estimated angle of every snapshot is within a grid step (+ the estimator's own spread) of the
+    direction it was generated with, and a sample of rows equals the oracle."""
+    N, K, P, M, B = 4, 1024, 1024, 1, 4096
+    streams, thetas = doa.sim.make_batch_streams_torch(N, K, B, 0.5, M, 20.0, seed=123)
+    mx = torch.empty((B, M), dtype=torch.float32, device="cuda")
+    am = torch.empty((B, M), dtype=torch.float32, device="cuda")
+    spec = torch.empty((B, P), dtype=torch.float32, device="cuda")
+    pipe = doa.music_pipeline(N, K, 0, 0, 0.5, M, P, max_batch=B)
+    assert pipe.work_dev(B, [s.data_ptr() for s in streams], 0, spec.data_ptr(), mx.data_ptr(), am.data_ptr(),
+                         torch.cuda.current_stream()) == B
+    torch.cuda.synchronize()
+    est = am.cpu().numpy()[:, 0]
+    assert np.abs(est - thetas[:, 0]).max() <= 1.0
+    assert np.all(mx.cpu().numpy() == 0.0)                     # M == 1: the global maximum is 0 dB
+    sample = slice(0, 64)
+    x = np.stack([s[: 64 * K].cpu().numpy() for s in streams])
+    _, s32, v0, loc = oracle.music_pipeline(x, K, 0, 0, 0.5, M, P, 64)
+    assert np.abs(est[sample] - loc[:, 0]).max() <= 180.0 / P + 1e-3
+
+
+def test_pipeline_rejects_oversized_batch():
+    pipe = doa.music_pipeline(4, 64, 0, 0, 0.5, 1, 64, max_batch=8)
+    with pytest.raises(doa.DoaError):
+        pipe.work_dev(9, [1, 1, 1, 1], 0, 0, 1, 1, None)

@@ -1,0 +1,75 @@
+"""GPU parity of K6 (doa.rootMUSIC_linear_array) against the oracle.
+
+Root-MUSIC's selected roots sit within ~1e-4 of their mirror images 1/conj(z); a float32 solver
+(the reference's LAPACK cgeev) is therefore itself only ~0.01 deg accurate, so the
+1e-3 deg target is only meaningful against the fp64 evaluation of the same formulas.  Bars:
+  * |angle_hip - angle_f64| <= 1e-3 deg on well-conditioned (noisy) scenarios,
+  * |angle_hip - angle_f32oracle| <= |angle_f32oracle - angle_f64| + 1e-3 deg everywhere
+    (never further from the reference than the reference is from the truth),
+  * the reference's QA floor: within 2.0 deg of the simulated direction
+    (python/qa_rootMUSIC_linear_array.py:87).
+"""
+import numpy as np
+import pytest
+
+import doa
+import doa_oracle as oracle
+from scenarios import SCENARIOS, make_input, is_rank_deficient
+
+pytestmark = pytest.mark.gpu
+
+ROOT_CASES = ["qa_root_aoa23", "qa_root_aoa52", "grc_root_sim", "bench_cfg3", "bench_cfg2", "low_snr",
+              "two_ant", "three_ant_fb", "five_ant", "bench_cfg4", "twelve_ant"]
+
+
+@pytest.mark.parametrize("name", ROOT_CASES)
+def test_root_music_matches_oracle(name):
+    c, x = make_input(name)
+    N, M, n = c["N"], c["M"], c["n"]
+    R = oracle.autocorrelate(x, c["K"], c["ovl"], c["fb"], n)
+    a32 = oracle.root_music(R, c["d"], M, N, "f32")
+    a64 = oracle.root_music(R, c["d"], M, N, "f64")
+    blk = doa.rootMUSIC_linear_array(c["d"], M, N)
+    got = np.empty((n, M), np.float32)
+    assert blk.work(n, [R], [got]) == n
+    assert np.all(np.diff(got, axis=1) >= 0)                                  # ascending (:144)
+    assert np.all(np.abs(got - np.sort(np.asarray(c["thetas"], np.float32))[None, :]) <= 2.0)
+    ref_dev = np.abs(a32.astype(np.float64) - a64)
+    if not is_rank_deficient(c):
+        assert np.abs(got - a64).max() <= 1e-3, (name, np.abs(got - a64).max())
+    assert np.all(np.abs(got - a32) <= ref_dev + np.abs(got - a64) + 1e-6)
+    assert np.abs(got - a64).max() <= max(1e-3, 2 * ref_dev.max()), (name, np.abs(got - a64).max(), ref_dev.max())
+
+
+def test_root_music_reference_qa_flowgraph():
+    """python/qa_rootMUSIC_linear_array.py:41-91: vector_source -> rootMUSIC -> sink, 2.0 deg."""
+    c, x = make_input("qa_root_aoa23")
+    R = oracle.autocorrelate(x, c["K"], c["ovl"], c["fb"], c["n"])
+    tb = doa.runtime.top_block()
+    src = doa.runtime.vector_source_c(R.reshape(-1), False, c["N"] ** 2)
+    blk = doa.rootMUSIC_linear_array(c["d"], c["M"], c["N"])
+    sink = doa.runtime.vector_sink_f(1)
+    tb.connect((src, 0), (blk, 0))
+    tb.connect((blk, 0), (sink, 0))
+    tb.run()
+    aoa = sink.data()
+    assert aoa.shape[0] == c["n"] and np.all(np.abs(aoa - 23.0) <= 2.0)
+
+
+def test_root_music_no_interior_root_is_an_error():
+    # P_N = 0 would give the zero polynomial; use R = I with M = N-1 on a crafted matrix whose
+    # noise vector yields roots exactly on the circle is fragile, so instead check the status path
+    # with NaN input: every comparison fails -> no root is "inside"
+    N, M = 4, 1
+    R = np.full((2, N * N), np.nan + 0j, dtype=np.complex64)
+    blk = doa.rootMUSIC_linear_array(0.5, M, N)
+    out = np.empty((2, M), np.float32)
+    with pytest.raises(doa.DoaError) as ei:
+        blk.work(2, [R], [out])
+    assert ei.value.status == -5
+
+
+def test_root_music_create_rejects_bad_arguments():
+    for args in [(0.5, 4, 4), (0.5, 0, 4), (0.7, 1, 4), (0.5, 1, 17)]:
+        with pytest.raises(doa.DoaError):
+            doa.rootMUSIC_linear_array(*args)
