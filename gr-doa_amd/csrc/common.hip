@@ -6,7 +6,7 @@
 namespace doa {
 
 static thread_local char g_err[512] = "";
-static std::atomic<int> g_evd_bits{64};
+static std::atomic<int> g_prec_bits{64};
 
 void set_error(const char *fmt, ...)
 {
@@ -74,7 +74,7 @@ void PinnedBuf::release()
     cap = 0;
 }
 
-int evd_precision_bits() { return g_evd_bits.load(); }
+int internal_precision_bits() { return g_prec_bits.load(); }
 
 }  // namespace doa
 
@@ -93,15 +93,15 @@ int doa_hip_device_count(void)
     return n;
 }
 
-int doa_set_evd_precision(int bits)
+int doa_set_internal_precision(int bits)
 {
     if (bits != 32 && bits != 64) {
-        doa::set_error("doa_set_evd_precision: bits must be 32 or 64 (got %d)", bits);
+        doa::set_error("doa_set_internal_precision: bits must be 32 or 64 (got %d)", bits);
         return DOA_ERR_INVALID_ARG;
     }
-    doa::g_evd_bits.store(bits);
+    doa::g_prec_bits.store(bits);
     return DOA_OK;
 }
-int doa_get_evd_precision(void) { return doa::g_evd_bits.load(); }
+int doa_get_internal_precision(void) { return doa::g_prec_bits.load(); }
 
 }  // extern "C"

@@ -47,7 +47,7 @@ struct PinnedBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
-int evd_precision_bits();  // 32 or 64 (doa_set_evd_precision)
+int internal_precision_bits();  // 32 or 64 (doa_set_internal_precision)
 
 // ---- device-side wave primitives (wave = 64 lanes on gfx950) -----------------------------------
 constexpr int kWave = 64;

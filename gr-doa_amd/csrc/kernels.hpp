@@ -13,19 +13,22 @@ int launch_autocorrelate(int N, int K, int ovl, int avg, int n_out, const void *
 struct MusicTables {
     int N = 0, M = 0, P = 0;
     float norm_spacing = 0.f;
-    DevBuf d_z;  // P float2
+    DevBuf d_z;   // P float2  (float scan)
+    DevBuf d_zd;  // P double2 (double scan)
     int build(float norm_spacing, int num_targets, int num_ant_ele, int pspectrum_len);
-    void release() { d_z.release(); }
+    void release() { d_z.release(); d_zd.release(); }
 };
 
 // coefficient record per item: [u0, Re u1, Im u1, ..., Re u_{N-1}, Im u_{N-1}, pad] = 2N floats
 inline int coef_stride(int N) { return 2 * N; }
 
-// K2+K3: batched Hermitian EVD + noise projector + diagonal sums.  d_pn may be NULL.
-int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_pn, int evd_bits,
-                     hipStream_t st);
-// K4: spectrum scan.  d_q (un-normalised null spectrum, P floats per item) may be NULL.
-int launch_music_scan(const MusicTables &t, int n_items, const void *d_coef, void *d_spec, void *d_q,
+// K2+K3: batched Hermitian EVD + noise projector + diagonal sums.  d_coef (float records, for the
+// scan), d_coef_d (double records, same layout, for the root finder) and d_pn may each be NULL.
+int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
+                     int evd_bits, hipStream_t st);
+// K4: spectrum scan in float (bits == 32, float coefficient records) or double (bits == 64, double
+// records).  d_q (un-normalised null spectrum, P floats per item) may be NULL.
+int launch_music_scan(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec, void *d_q,
                       hipStream_t st);
 
 // K5 (find_local_max.hip)
@@ -39,7 +42,7 @@ struct PeakTables {
 int launch_find_local_max(const PeakTables &t, int n_items, const void *d_in, void *d_max, void *d_argmax,
                           hipStream_t st);
 
-// K6 (root_music.hip): polynomial roots from the coefficient records -> angles.
+// K6 (root_music.hip): polynomial roots from the DOUBLE coefficient records -> angles.
 int launch_root_music(int N, int M, float norm_spacing, int n_items, const void *d_coef, void *d_out,
                       void *d_status, hipStream_t st);
 

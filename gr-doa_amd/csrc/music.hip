@@ -44,18 +44,23 @@ int MusicTables::build(float norm_spacing_, int num_targets, int num_ant_ele, in
         theta_prev = th;
         theta[ii] = (float)(M_PI * th / 180.0);
     }
-    // amv (:98-104): phase_n = float(-2 pi cos(theta)) * loc_n with loc_n = d*0.5*(N-1-2n); the
-    // phase step between neighbouring elements is psi = k*d.  z = exp(j psi) in double -> float.
+    // amv (:98-104): a_i[n] = exp(j * (-2 pi cos(theta_i)) * loc_n), loc_n = d*0.5*(N-1-2n) (:57-61), so
+    // the phase step between neighbouring elements is psi_i = -2 pi cos(theta_i) * d.  Evaluated in
+    // double from the float theta grid; the reference's float roundings of the scalar, of loc_n and of
+    // each phase (~2e-7 rad) are not replayed (they are part of its own fp32 error budget).
     std::vector<float2> z(P);
+    std::vector<double2> zd(P);
     const double d = (double)norm_spacing;
     for (int ii = 0; ii < P; ii++) {
-        const float k = (float)(-1.0 * 2 * M_PI * std::cos((double)theta[ii]));
-        const double psi = (double)k * d;
+        const double psi = -1.0 * 2 * M_PI * std::cos((double)theta[ii]) * d;
         z[ii] = make_float2((float)std::cos(psi), (float)std::sin(psi));
+        zd[ii] = make_double2(std::cos(psi), std::sin(psi));
     }
     int rc = d_z.reserve(sizeof(float2) * (size_t)P);
+    if (rc == DOA_OK) rc = d_zd.reserve(sizeof(double2) * (size_t)P);
     if (rc != DOA_OK) return rc;
     DOA_HIP_TRY(hipMemcpy(d_z.p, z.data(), sizeof(float2) * (size_t)P, hipMemcpyHostToDevice));
+    DOA_HIP_TRY(hipMemcpy(d_zd.p, zd.data(), sizeof(double2) * (size_t)P, hipMemcpyHostToDevice));
     return DOA_OK;
 }
 
@@ -162,7 +167,8 @@ __device__ __forceinline__ void herm_jacobi(T (&ar)[N][N], T (&ai)[N][N], T (&vr
 
 template <int N, typename T>
 __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
-                                                       float2 *__restrict__ pn_out, int n_items, int M)
+                                                       double *__restrict__ coef_d, float2 *__restrict__ pn_out,
+                                                       int n_items, int M)
 {
     constexpr bool UNROLL = (N <= 4);
     constexpr int U = UNROLL ? N : 1;
@@ -222,38 +228,46 @@ __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict_
 #pragma unroll U
             for (int r = 0; r < N; r++) po[r + c * N] = make_float2((float)ar[r][c], (float)ai[r][c]);
     }
-    // diagonal sums u_l = sum_r P_N[r+l][r]
-    float *co = coef + (size_t)item * (2 * N);
+    // diagonal sums u_l = sum_r P_N[r+l][r]; float record for the scan, double record for the root
+    // finder (Root-MUSIC's near-double roots amplify a float rounding of u_l by ~1e3-1e4)
+    float *co = coef ? coef + (size_t)item * (2 * N) : nullptr;
+    double *cd = coef_d ? coef_d + (size_t)item * (2 * N) : nullptr;
 #pragma unroll U
     for (int l = 0; l < N; l++) {
         T ur = 0, ui = 0;
 #pragma unroll U
         for (int r = 0; r < N; r++)
             if (r + l < N) { ur += ar[r + l][r]; ui += ai[r + l][r]; }
-        if (l == 0) co[0] = (float)ur;
-        else { co[2 * l - 1] = (float)ur; co[2 * l] = (float)ui; }
+        if (l == 0) {
+            if (co) co[0] = (float)ur;
+            if (cd) cd[0] = (double)ur;
+        } else {
+            if (co) { co[2 * l - 1] = (float)ur; co[2 * l] = (float)ui; }
+            if (cd) { cd[2 * l - 1] = (double)ur; cd[2 * l] = (double)ui; }
+        }
     }
-    co[2 * N - 1] = 0.f;
+    if (co) co[2 * N - 1] = 0.f;
+    if (cd) cd[2 * N - 1] = 0.0;
 }
 
-template <int N> static void launch_evd_n(int M, int n_items, const void *d_R, void *d_coef, void *d_pn, int bits,
-                                          hipStream_t st)
+template <int N> static void launch_evd_n(int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
+                                          int bits, hipStream_t st)
 {
     dim3 block(64), grid((n_items + 63) / 64);
     if (bits == 32)
         hipLaunchKernelGGL((music_evd_kernel<N, float>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,
-                           (float2 *)d_pn, n_items, M);
+                           (double *)d_coef_d, (float2 *)d_pn, n_items, M);
     else
         hipLaunchKernelGGL((music_evd_kernel<N, double>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,
-                           (float2 *)d_pn, n_items, M);
+                           (double *)d_coef_d, (float2 *)d_pn, n_items, M);
 }
 
-int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_pn, int evd_bits,
-                     hipStream_t st)
+int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
+                     int evd_bits, hipStream_t st)
 {
     if (n_items <= 0) return DOA_OK;
     switch (N) {
-#define DOA_EVD_CASE(n) case n: launch_evd_n<n>(M, n_items, d_R, d_coef, d_pn, evd_bits, st); break;
+#define DOA_EVD_CASE(n) case n: launch_evd_n<n>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
         DOA_EVD_CASE(2) DOA_EVD_CASE(3) DOA_EVD_CASE(4) DOA_EVD_CASE(5) DOA_EVD_CASE(6) DOA_EVD_CASE(7)
         DOA_EVD_CASE(8) DOA_EVD_CASE(9) DOA_EVD_CASE(10) DOA_EVD_CASE(11) DOA_EVD_CASE(12) DOA_EVD_CASE(13)
         DOA_EVD_CASE(14) DOA_EVD_CASE(15) DOA_EVD_CASE(16)
@@ -269,57 +283,55 @@ int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, v
 // ---------------------------------------------------------------------------------------------
 // K4: spectrum scan
 // ---------------------------------------------------------------------------------------------
-// Q = u0 + 2 Re( sum_{l=1}^{N-1} u_l z^l ) by Horner.  co points at the item's coefficient record.
-template <int N> __device__ __forceinline__ float null_spectrum(const float *__restrict__ co, float zr, float zi)
+// Q = u0 + 2 Re( sum_{l=1}^{N-1} u_l z^l ) by Horner, in T (float or double).  c = the item's
+// coefficient record [u0, Re u1, Im u1, ...].
+template <int N, typename T> __device__ __forceinline__ T null_spectrum(const T (&c)[2 * N], T zr, T zi)
 {
-    if constexpr (N == 1) return co[0];
-    float hr = co[2 * (N - 1) - 1], hi = co[2 * (N - 1)];
+    if constexpr (N == 1) return c[0];
+    T hr = c[2 * (N - 1) - 1], hi = c[2 * (N - 1)];
 #pragma unroll
     for (int l = N - 2; l >= 1; l--) {
-        const float tr = fmaf(hr, zr, fmaf(-hi, zi, co[2 * l - 1]));
-        const float ti = fmaf(hr, zi, fmaf(hi, zr, co[2 * l]));
+        const T tr = fma(hr, zr, fma(-hi, zi, c[2 * l - 1]));
+        const T ti = fma(hr, zi, fma(hi, zr, c[2 * l]));
         hr = tr; hi = ti;
     }
-    const float re = fmaf(hr, zr, -hi * zi);
-    return fmaf(2.0f, re, co[0]);
+    const T re = fma(hr, zr, -hi * zi);
+    return fma((T)2, re, c[0]);
 }
 
 __device__ __forceinline__ float db_from_ratio(float out, float mx, float inv_mx)
 {
-    // 10*log10(out/max): the maximum itself must come out as exactly 0 dB (x/x == 1 in the
-    // reference), everything else as out * (1/max) through the hardware log2.
-    float ratio = (out == mx) ? 1.0f : out * inv_mx;
+    // 10*log10(out/max).  The maximum itself must come out as exactly 0 dB (x/x == 1 in the
+    // reference; inf/inf stays NaN as there), everything else is out*(1/max) through the hardware
+    // log2: 10*log10(r) = (10*log10(2)) * log2(r).
+    float ratio = (out == mx && mx != INFINITY) ? 1.0f : out * inv_mx;
     return 3.0102999566398120f * __log2f(ratio);
 }
 
 // Fast path: P % 4 == 0 and P <= 256*CH.  One wave per item, grid-stride over items so that the
-// z table (4*CH angles per lane) is loaded once per wave.
-template <int N, int CH>
-__global__ __launch_bounds__(256) void music_scan_kernel(const float *__restrict__ coef, const float2 *__restrict__ ztab,
+// z table (4*CH angles per lane) is loaded once per wave and stays in registers.
+template <int N, int CH, typename T>
+__global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                          float *__restrict__ spec, float *__restrict__ qout, int P,
                                                          int n_items)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
     const int n_waves = gridDim.x * (blockDim.x / kWave);
 
-    float zr[CH][4], zi[CH][4];
+    T zr[CH][4], zi[CH][4];
 #pragma unroll
     for (int j = 0; j < CH; j++) {
         const int i0 = 4 * lane + 256 * j;
-        if (i0 < P) {
-            const float4 a = *reinterpret_cast<const float4 *>(ztab + i0);
-            const float4 b = *reinterpret_cast<const float4 *>(ztab + i0 + 2);
-            zr[j][0] = a.x; zi[j][0] = a.y; zr[j][1] = a.z; zi[j][1] = a.w;
-            zr[j][2] = b.x; zi[j][2] = b.y; zr[j][3] = b.z; zi[j][3] = b.w;
-        } else {
 #pragma unroll
-            for (int e = 0; e < 4; e++) { zr[j][e] = 1.f; zi[j][e] = 0.f; }
+        for (int e = 0; e < 4; e++) {
+            if (i0 < P) { zr[j][e] = ztab[2 * (i0 + e)]; zi[j][e] = ztab[2 * (i0 + e) + 1]; }
+            else { zr[j][e] = 1; zi[j][e] = 0; }
         }
     }
     for (int item = wave; item < n_items; item += n_waves) {
-        const float *co = coef + (size_t)item * (2 * N);   // wave-uniform -> scalar loads
-        float c[2 * N];
+        const T *co = coef + (size_t)item * (2 * N);   // wave-uniform address -> scalar loads
+        T c[2 * N];
 #pragma unroll
         for (int k = 0; k < 2 * N; k++) c[k] = co[k];
         float out[CH][4];
@@ -329,9 +341,9 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const float *__restrict
             const bool live = (4 * lane + 256 * j) < P;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const float q = null_spectrum<N>(c, zr[j][e], zi[j][e]);
+                const float q = (float)null_spectrum<N, T>(c, zr[j][e], zi[j][e]);
                 if (qout && live) qout[(size_t)item * P + 4 * lane + 256 * j + e] = q;
-                out[j][e] = __builtin_amdgcn_rcpf(q);           // 1.0/Q
+                out[j][e] = __builtin_amdgcn_rcpf(q);           // 1.0/Q  (:140)
                 if (live) mx = fmaxf(mx, out[j][e]);
             }
         }
@@ -354,70 +366,75 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const float *__restrict
 }
 
 // Any P: one wave per item, one angle per lane per step, two passes (max, then write).
-template <int N>
-__global__ __launch_bounds__(256) void music_scan_generic_kernel(const float *__restrict__ coef,
-                                                                 const float2 *__restrict__ ztab, float *__restrict__ spec,
-                                                                 float *__restrict__ qout, int P, int n_items)
+template <int N, typename T>
+__global__ __launch_bounds__(256) void music_scan_generic_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
+                                                                 float *__restrict__ spec, float *__restrict__ qout, int P,
+                                                                 int n_items)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
     const int n_waves = gridDim.x * (blockDim.x / kWave);
     for (int item = wave; item < n_items; item += n_waves) {
-        const float *co = coef + (size_t)item * (2 * N);
-        float c[2 * N];
+        const T *co = coef + (size_t)item * (2 * N);
+        T c[2 * N];
 #pragma unroll
         for (int k = 0; k < 2 * N; k++) c[k] = co[k];
         float mx = -INFINITY;
         for (int i = lane; i < P; i += kWave) {
-            const float2 z = ztab[i];
-            const float q = null_spectrum<N>(c, z.x, z.y);
+            const float q = (float)null_spectrum<N, T>(c, ztab[2 * i], ztab[2 * i + 1]);
             if (qout) qout[(size_t)item * P + i] = q;
             mx = fmaxf(mx, __builtin_amdgcn_rcpf(q));
         }
         mx = wave_allreduce_max(mx);
         const float inv_mx = __builtin_amdgcn_rcpf(mx);
         for (int i = lane; i < P; i += kWave) {
-            const float2 z = ztab[i];
-            const float o = __builtin_amdgcn_rcpf(null_spectrum<N>(c, z.x, z.y));
+            const float o = __builtin_amdgcn_rcpf((float)null_spectrum<N, T>(c, ztab[2 * i], ztab[2 * i + 1]));
             spec[(size_t)item * P + i] = db_from_ratio(o, mx, inv_mx);
         }
     }
 }
 
-template <int N> static void launch_scan_n(const MusicTables &t, int n_items, const void *d_coef, void *d_spec,
-                                           void *d_q, hipStream_t st)
+template <int N, typename T>
+static void launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_spec, void *d_q, hipStream_t st)
 {
-    const int P = t.P;
-    const float *co = (const float *)d_coef;
-    const float2 *z = t.d_z.as<float2>();
     float *sp = (float *)d_spec, *q = (float *)d_q;
     const int waves_per_block = 4;
     const bool aligned = (P % 4 == 0) && (reinterpret_cast<uintptr_t>(d_spec) % 16 == 0);
-    // enough waves to fill the chip several times over, but few enough that each wave amortises its
+    // enough waves to fill the chip several times over, few enough that each wave amortises its
     // z-table load over several items
     int blocks = (n_items + waves_per_block - 1) / waves_per_block;
     const int max_blocks = 256 * 8;
     if (blocks > max_blocks) blocks = max_blocks;
     dim3 grid(blocks), block(waves_per_block * kWave);
     if (aligned && P <= 256)
-        hipLaunchKernelGGL((music_scan_kernel<N, 1>), grid, block, 0, st, co, z, sp, q, P, n_items);
+        hipLaunchKernelGGL((music_scan_kernel<N, 1, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
     else if (aligned && P <= 512)
-        hipLaunchKernelGGL((music_scan_kernel<N, 2>), grid, block, 0, st, co, z, sp, q, P, n_items);
+        hipLaunchKernelGGL((music_scan_kernel<N, 2, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
     else if (aligned && P <= 1024)
-        hipLaunchKernelGGL((music_scan_kernel<N, 4>), grid, block, 0, st, co, z, sp, q, P, n_items);
-    else if (aligned && P <= 2048)
-        hipLaunchKernelGGL((music_scan_kernel<N, 8>), grid, block, 0, st, co, z, sp, q, P, n_items);
-    else if (aligned && P <= 4096)
-        hipLaunchKernelGGL((music_scan_kernel<N, 16>), grid, block, 0, st, co, z, sp, q, P, n_items);
+        hipLaunchKernelGGL((music_scan_kernel<N, 4, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
+    else if (aligned && P <= 2048 && sizeof(T) == 4)
+        hipLaunchKernelGGL((music_scan_kernel<N, 8, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
+    else if (aligned && P <= 4096 && sizeof(T) == 4)
+        hipLaunchKernelGGL((music_scan_kernel<N, 16, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
     else
-        hipLaunchKernelGGL((music_scan_generic_kernel<N>), grid, block, 0, st, co, z, sp, q, P, n_items);
+        hipLaunchKernelGGL((music_scan_generic_kernel<N, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
 }
 
-int launch_music_scan(const MusicTables &t, int n_items, const void *d_coef, void *d_spec, void *d_q, hipStream_t st)
+template <int N> static void launch_scan_n(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec,
+                                           void *d_q, hipStream_t st)
+{
+    if (bits == 32)
+        launch_scan_nt<N, float>((const float *)d_coef, t.d_z.as<float>(), t.P, n_items, d_spec, d_q, st);
+    else
+        launch_scan_nt<N, double>((const double *)d_coef, t.d_zd.as<double>(), t.P, n_items, d_spec, d_q, st);
+}
+
+int launch_music_scan(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec, void *d_q,
+                      hipStream_t st)
 {
     if (n_items <= 0) return DOA_OK;
     switch (t.N) {
-#define DOA_SCAN_CASE(n) case n: launch_scan_n<n>(t, n_items, d_coef, d_spec, d_q, st); break;
+#define DOA_SCAN_CASE(n) case n: launch_scan_n<n>(t, bits, n_items, d_coef, d_spec, d_q, st); break;
         DOA_SCAN_CASE(2) DOA_SCAN_CASE(3) DOA_SCAN_CASE(4) DOA_SCAN_CASE(5) DOA_SCAN_CASE(6) DOA_SCAN_CASE(7)
         DOA_SCAN_CASE(8) DOA_SCAN_CASE(9) DOA_SCAN_CASE(10) DOA_SCAN_CASE(11) DOA_SCAN_CASE(12) DOA_SCAN_CASE(13)
         DOA_SCAN_CASE(14) DOA_SCAN_CASE(15) DOA_SCAN_CASE(16)
@@ -437,7 +454,7 @@ int launch_music_scan(const MusicTables &t, int n_items, const void *d_coef, voi
 // ---------------------------------------------------------------------------------------------
 struct doa_MUSIC_lin_array {
     doa::MusicTables tab;
-    int evd_bits = 64;
+    int bits = 64;   // internal precision of EVD + scan (doa_set_internal_precision)
     int device = 0;
     long long items_total = 0;
     hipStream_t stream = nullptr;
@@ -479,7 +496,7 @@ doa_MUSIC_lin_array_t *doa_MUSIC_lin_array_create(float norm_spacing, int num_ta
     auto *h = new (std::nothrow) doa_MUSIC_lin_array();
     if (!h) { doa::set_error("out of memory"); return nullptr; }
     h->device = dev;
-    h->evd_bits = doa::evd_precision_bits();
+    h->bits = doa::internal_precision_bits();
     if (h->tab.build(norm_spacing, num_targets, num_ant_ele, pspectrum_len) != DOA_OK ||
         hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         if (!*doa_last_error()) doa::set_error("MUSIC_lin_array: device setup failed");
@@ -511,11 +528,13 @@ int doa_MUSIC_lin_array_work_dev(doa_MUSIC_lin_array_t *h, int noutput_items, co
     if (noutput_items == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const int N = h->tab.N;
-    int rc = h->d_coef.reserve((size_t)noutput_items * doa::coef_stride(N) * sizeof(float));
+    int rc = h->d_coef.reserve((size_t)noutput_items * doa::coef_stride(N) * sizeof(double));
     if (rc != DOA_OK) return rc;
-    rc = doa::launch_music_evd(N, h->tab.M, noutput_items, d_input_items0, h->d_coef.p, nullptr, h->evd_bits, st);
+    const bool dbl = (h->bits == 64);
+    rc = doa::launch_music_evd(N, h->tab.M, noutput_items, d_input_items0, dbl ? nullptr : h->d_coef.p,
+                               dbl ? h->d_coef.p : nullptr, nullptr, h->bits, st);
     if (rc != DOA_OK) return rc;
-    rc = doa::launch_music_scan(h->tab, noutput_items, h->d_coef.p, d_output_items0, nullptr, st);
+    rc = doa::launch_music_scan(h->tab, h->bits, noutput_items, h->d_coef.p, d_output_items0, nullptr, st);
     if (rc != DOA_OK) return rc;
     h->items_total += noutput_items;
     return noutput_items;
@@ -559,12 +578,14 @@ int doa_MUSIC_lin_array_debug(doa_MUSIC_lin_array_t *h, int noutput_items, const
     if (rc == DOA_OK) rc = h->d_out.reserve(sp_bytes);
     if (rc == DOA_OK) rc = h->d_q.reserve(sp_bytes);
     if (rc == DOA_OK) rc = h->d_pn.reserve(in_bytes);
-    if (rc == DOA_OK) rc = h->d_coef.reserve((size_t)noutput_items * doa::coef_stride(N) * sizeof(float));
+    if (rc == DOA_OK) rc = h->d_coef.reserve((size_t)noutput_items * doa::coef_stride(N) * sizeof(double));
     if (rc != DOA_OK) return rc;
     DOA_HIP_TRY(hipMemcpyAsync(h->d_in.p, input_items0, in_bytes, hipMemcpyHostToDevice, h->stream));
-    rc = doa::launch_music_evd(N, h->tab.M, noutput_items, h->d_in.p, h->d_coef.p, h->d_pn.p, h->evd_bits, h->stream);
+    const bool dbl = (h->bits == 64);
+    rc = doa::launch_music_evd(N, h->tab.M, noutput_items, h->d_in.p, dbl ? nullptr : h->d_coef.p,
+                               dbl ? h->d_coef.p : nullptr, h->d_pn.p, h->bits, h->stream);
     if (rc != DOA_OK) return rc;
-    rc = doa::launch_music_scan(h->tab, noutput_items, h->d_coef.p, h->d_out.p, h->d_q.p, h->stream);
+    rc = doa::launch_music_scan(h->tab, h->bits, noutput_items, h->d_coef.p, h->d_out.p, h->d_q.p, h->stream);
     if (rc != DOA_OK) return rc;
     if (projector_out)
         DOA_HIP_TRY(hipMemcpyAsync(projector_out, h->d_pn.p, in_bytes, hipMemcpyDeviceToHost, h->stream));

@@ -17,7 +17,7 @@ int launch_find_local_max_serial(const PeakTables &t, int n_items, const void *d
 struct doa_music_pipeline {
     int N = 0, K = 0, ovl = 0, avg = 0;
     int max_batch = 0;
-    int evd_bits = 64;
+    int bits = 64;
     int device = 0;
     doa::MusicTables music;
     doa::PeakTables peaks;
@@ -49,11 +49,11 @@ doa_music_pipeline_t *doa_music_pipeline_create(int inputs, int snapshot_size, i
     if (!h) { doa::set_error("out of memory"); return nullptr; }
     h->N = inputs; h->K = snapshot_size; h->ovl = overlap_size; h->avg = avg_method;
     h->max_batch = max_batch; h->device = dev;
-    h->evd_bits = doa::evd_precision_bits();
+    h->bits = doa::internal_precision_bits();
     int rc = h->music.build(norm_spacing, num_targets, inputs, pspectrum_len);
     if (rc == DOA_OK) rc = h->peaks.build(num_targets, pspectrum_len, 0.0f, 180.0f);
     if (rc == DOA_OK) rc = h->d_cov.reserve((size_t)max_batch * inputs * inputs * sizeof(float2));
-    if (rc == DOA_OK) rc = h->d_coef.reserve((size_t)max_batch * doa::coef_stride(inputs) * sizeof(float));
+    if (rc == DOA_OK) rc = h->d_coef.reserve((size_t)max_batch * doa::coef_stride(inputs) * sizeof(double));
     if (rc == DOA_OK) rc = h->d_spec.reserve((size_t)max_batch * pspectrum_len * sizeof(float));
     if (rc != DOA_OK) {
         doa_music_pipeline_destroy(h);
@@ -90,9 +90,11 @@ int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput_items, cons
     void *spec = d_spectrum_out ? d_spectrum_out : h->d_spec.p;
     int rc = doa::launch_autocorrelate(h->N, h->K, h->ovl, h->avg, noutput_items, d_input_items, cov, st);
     if (rc != DOA_OK) return rc;
-    rc = doa::launch_music_evd(h->N, h->music.M, noutput_items, cov, h->d_coef.p, nullptr, h->evd_bits, st);
+    const bool dbl = (h->bits == 64);
+    rc = doa::launch_music_evd(h->N, h->music.M, noutput_items, cov, dbl ? nullptr : h->d_coef.p,
+                               dbl ? h->d_coef.p : nullptr, nullptr, h->bits, st);
     if (rc != DOA_OK) return rc;
-    rc = doa::launch_music_scan(h->music, noutput_items, h->d_coef.p, spec, nullptr, st);
+    rc = doa::launch_music_scan(h->music, h->bits, noutput_items, h->d_coef.p, spec, nullptr, st);
     if (rc != DOA_OK) return rc;
     if (doa::find_local_max_fast_ok(h->peaks.L, spec)) {
         rc = doa::launch_find_local_max(h->peaks, noutput_items, spec, d_max_out, d_argmax_out, st);

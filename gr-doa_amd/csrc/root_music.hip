@@ -73,12 +73,12 @@ __device__ __forceinline__ void aberth_roots(const double (&cr)[2 * N - 1], cons
             const double rel = (er * er + ei * ei) / (1.0 + zr[k] * zr[k] + zi[k] * zi[k]);
             worst = fmax(worst, rel);
         }
-        if (worst < 1e-30) break;
+        if (worst < 1e-29) break;   // squared relative step: steps below ~3e-15 are rounding noise
     }
 }
 
 template <int N>
-__global__ __launch_bounds__(64) void root_music_kernel(const float *__restrict__ coef, float *__restrict__ out,
+__global__ __launch_bounds__(64) void root_music_kernel(const double *__restrict__ coef, float *__restrict__ out,
                                                         int *__restrict__ status, int n_items, int M, double two_pi_d)
 {
     constexpr bool UNROLL = (N <= 4);
@@ -86,13 +86,13 @@ __global__ __launch_bounds__(64) void root_music_kernel(const float *__restrict_
     constexpr int U = UNROLL ? D : 1;
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= n_items) return;
-    const float *co = coef + (size_t)item * (2 * N);
+    const double *co = coef + (size_t)item * (2 * N);
     // polynomial c[k], k = 0..2N-2: c[N-1-l] = u_l, c[N-1+l] = conj(u_l)   (:71-78)
     double cr[2 * N - 1], ci[2 * N - 1];
-    cr[N - 1] = (double)co[0]; ci[N - 1] = 0.0;
+    cr[N - 1] = co[0]; ci[N - 1] = 0.0;
 #pragma unroll U
     for (int l = 1; l < N; l++) {
-        const double ur = (double)co[2 * l - 1], ui = (double)co[2 * l];
+        const double ur = co[2 * l - 1], ui = co[2 * l];
         cr[N - 1 - l] = ur; ci[N - 1 - l] = ui;
         cr[N - 1 + l] = ur; ci[N - 1 + l] = -ui;
     }
@@ -148,7 +148,7 @@ int launch_root_music(int N, int M, float norm_spacing, int n_items, const void 
     switch (N) {
 #define DOA_ROOT_CASE(n)                                                                                   \
     case n:                                                                                                \
-        hipLaunchKernelGGL(root_music_kernel<n>, grid, block, 0, st, (const float *)d_coef, (float *)d_out, \
+        hipLaunchKernelGGL(root_music_kernel<n>, grid, block, 0, st, (const double *)d_coef, (float *)d_out, \
                            (int *)d_status, n_items, M, two_pi_d);                                         \
         break;
         DOA_ROOT_CASE(2) DOA_ROOT_CASE(3) DOA_ROOT_CASE(4) DOA_ROOT_CASE(5) DOA_ROOT_CASE(6) DOA_ROOT_CASE(7)
@@ -171,7 +171,7 @@ int launch_root_music(int N, int M, float norm_spacing, int n_items, const void 
 struct doa_rootMUSIC_linear_array {
     float norm_spacing = 0.f;
     int M = 0, N = 0;
-    int evd_bits = 64;
+    int bits = 64;
     int device = 0;
     hipStream_t stream = nullptr;
     doa::DevBuf d_in, d_out, d_coef, d_status;
@@ -202,7 +202,7 @@ doa_rootMUSIC_linear_array_t *doa_rootMUSIC_linear_array_create(float norm_spaci
     auto *h = new (std::nothrow) doa_rootMUSIC_linear_array();
     if (!h) { doa::set_error("out of memory"); return nullptr; }
     h->norm_spacing = norm_spacing; h->M = num_targets; h->N = num_ant_ele; h->device = dev;
-    h->evd_bits = doa::evd_precision_bits();
+    h->bits = doa::internal_precision_bits();
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         doa::set_error("rootMUSIC_linear_array: hipStreamCreate failed");
         delete h;
@@ -229,10 +229,10 @@ int doa_rootMUSIC_linear_array_work_dev(doa_rootMUSIC_linear_array_t *h, int nou
     }
     if (noutput_items == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    int rc = h->d_coef.reserve((size_t)noutput_items * doa::coef_stride(h->N) * sizeof(float));
+    int rc = h->d_coef.reserve((size_t)noutput_items * doa::coef_stride(h->N) * sizeof(double));
     if (rc == DOA_OK) rc = h->d_status.reserve((size_t)noutput_items * sizeof(int));
     if (rc != DOA_OK) return rc;
-    rc = doa::launch_music_evd(h->N, h->M, noutput_items, d_input_items0, h->d_coef.p, nullptr, h->evd_bits, st);
+    rc = doa::launch_music_evd(h->N, h->M, noutput_items, d_input_items0, nullptr, h->d_coef.p, nullptr, h->bits, st);
     if (rc != DOA_OK) return rc;
     rc = doa::launch_root_music(h->N, h->M, h->norm_spacing, noutput_items, h->d_coef.p, d_output_items0,
                                 h->d_status.p, st);

@@ -27,6 +27,29 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: build the HIP extension first (make -C gr-doa_amd, or "
         f"python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
 
+
+
+def _preload_torch_hip_runtime() -> None:
+    """PyTorch's ROCm wheel ships its own libamdhip64.so / libhsa-runtime64.so (same SONAMEs as
+    /opt/rocm's).  Two HSA runtimes in one process cannot both open the GPU, so when torch is
+    installed its runtime is loaded first and libdoa_hip.so's DT_NEEDED `libamdhip64.so.7` binds
+    to it; without torch the library binds to /opt/rocm through its RUNPATH (the C++ deployment).
+    Set DOA_HIP_SYSTEM_RUNTIME=1 to skip this (then do not import torch in the same process)."""
+    if os.environ.get("DOA_HIP_SYSTEM_RUNTIME"):
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+_preload_torch_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 _vp = C.c_void_p
@@ -37,8 +60,8 @@ SIGNATURES = {
     "doa_last_error": (C.c_char_p, []),
     "doa_hip_abi_version": (C.c_int, []),
     "doa_hip_device_count": (C.c_int, []),
-    "doa_set_evd_precision": (C.c_int, [C.c_int]),
-    "doa_get_evd_precision": (C.c_int, []),
+    "doa_set_internal_precision": (C.c_int, [C.c_int]),
+    "doa_get_internal_precision": (C.c_int, []),
     "doa_autocorrelate_create": (_vp, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "doa_autocorrelate_destroy": (None, [_vp]),
     "doa_autocorrelate_history": (C.c_int, [_vp]),

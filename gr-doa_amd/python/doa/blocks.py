@@ -229,12 +229,12 @@ class music_pipeline(_Block):
             _stream_ptr(stream)))
 
 
-def set_evd_precision(bits: int) -> None:
-    check(lib.doa_set_evd_precision(int(bits)))
+def set_internal_precision(bits: int) -> None:
+    check(lib.doa_set_internal_precision(int(bits)))
 
 
-def get_evd_precision() -> int:
-    return int(lib.doa_get_evd_precision())
+def get_internal_precision() -> int:
+    return int(lib.doa_get_internal_precision())
 
 
 def device_count() -> int:

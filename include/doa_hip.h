@@ -66,11 +66,13 @@ DOA_HIP_API int doa_hip_abi_version(void);
 /* Number of visible HIP devices (0 if none / runtime unusable). Does not create a context. */
 DOA_HIP_API int doa_hip_device_count(void);
 
-/* Precision of the batched Hermitian eigendecomposition used by MUSIC / Root-MUSIC handles
- * created *after* the call: 32 = float Jacobi, 64 = double Jacobi (default).  Inputs and outputs
- * stay complex64 / float32 either way.  Returns DOA_OK or DOA_ERR_INVALID_ARG. */
-DOA_HIP_API int doa_set_evd_precision(int bits);
-DOA_HIP_API int doa_get_evd_precision(void);
+/* Internal precision of the batched Hermitian eigendecomposition and of the null-spectrum
+ * evaluation used by MUSIC / Root-MUSIC / pipeline handles created *after* the call:
+ * 64 (default) = double Jacobi + double Horner scan, 32 = float for both.  Item formats stay
+ * complex64 in / float32 out either way; Root-MUSIC always finds its roots in double.
+ * Returns DOA_OK or DOA_ERR_INVALID_ARG. */
+DOA_HIP_API int doa_set_internal_precision(int bits);
+DOA_HIP_API int doa_get_internal_precision(void);
 
 /* ---------------------------------------------------------------------------------------------
  * autocorrelate — gr::doa::autocorrelate::make(inputs, snapshot_size, overlap_size, avg_method)

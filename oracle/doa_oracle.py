@@ -127,8 +127,9 @@ def music_steering(norm_spacing: float, num_ant_ele: int, pspectrum_len: int,
     amv: v = exp(i * ((-1.0*2*pi*cos(theta)) * array_loc)); the scalar is a double expression
     that Armadillo casts to float when it scales the fcolvec, the product scalar*loc is a float
     multiply, and exp is std::exp(complex<float>) = (cosf(y), sinf(y)) for a zero real part.
-    precision="f64" evaluates the same grid/locations (which are *defined* in float) with double
-    phases and double exp — the reference's formula without its float rounding.
+    precision="f64" is the formula itself in double: the float-accumulated theta grid is kept (it
+    is a stored float member and a documented quirk of the block), but the element positions
+    d*0.5*(N-1-2n), the scalar -2*pi*cos(theta), the phases and exp are not rounded to float.
     """
     loc = music_array_loc(norm_spacing, num_ant_ele)
     theta = music_theta_grid(pspectrum_len)
@@ -136,8 +137,10 @@ def music_steering(norm_spacing: float, num_ant_ele: int, pspectrum_len: int,
         k = (-1.0 * 2 * np.pi * np.cos(theta.astype(np.float64))).astype(_F32)   # scalar -> float
         phase = (k[None, :] * loc[:, None]).astype(_F32)                          # float multiply
         return (np.cos(phase) + 1j * np.sin(phase)).astype(_C64)
+    d = float(_F32(norm_spacing))
+    loc64 = np.array([d * 0.5 * (num_ant_ele - 1 - 2 * nn) for nn in range(num_ant_ele)], dtype=np.float64)
     k = -1.0 * 2 * np.pi * np.cos(theta.astype(np.float64))
-    phase = k[None, :] * loc.astype(np.float64)[:, None]
+    phase = k[None, :] * loc64[:, None]
     return np.cos(phase) + 1j * np.sin(phase)
 
 

@@ -2,20 +2,24 @@
 
 What "parity" means for this floating-point block.  The block's
 output is 10*log10(out/max(out)) with out = 1/Q; the maximum sits at a null of Q where
-Q ~ 1e-5..1e-7 is cancellation-dominated, so two *correct* fp32 evaluations (even two BLAS
-orderings of the reference itself) disagree there by ~1 % and the whole normalised spectrum shifts
-by ~0.01-0.1 dB.  The tests therefore pin, per item,
-  (a) the noise projector:  |P_hip - P_f64| <= 1e-6 (double EVD) resp. within 4x of the LAPACK-fp32
-      oracle's own distance to fp64 (float EVD);
-  (b) the null spectrum where it is well conditioned (Q >= 1e-2 max Q):
-      |Q_hip - Q_f64|/Q <= 3e-6, and |Q_hip - Q_f32oracle|/Q <= 1e-5 (north_star) unless the
-      fp32 oracle itself is further than that from fp64;
-  (c) everywhere: |Q_hip - Q_f64| <= 4 max|Q_f32oracle - Q_f64| + 1e-6 max Q  (never worse than the
-      reference's own rounding);
-  (d) the dB spectrum: its maximum is exactly 0 dB, and up to the one normalisation constant it
-      matches fp64 within 5e-5 dB where (b) applies;
-  (e) the arg-max bins (= angles through find_local_max) equal the oracle's — exactly for
-      noisy data, within one 180/P bin for the rank-deficient scenarios.
+Q ~ 1e-5..1e-7 of its full scale is cancellation-dominated in float, so two *correct* fp32
+evaluations (even two BLAS orderings of the reference itself) disagree there by ~1 % and the whole
+normalised spectrum shifts by ~0.01-0.1 dB (measured: tools/diag_parity.py).  The reference's own
+fp32 rounding is therefore the floor of any comparison against it; what can be pinned tightly is
+the distance to the fp64 evaluation of the same formulas on the same inputs.
+
+internal precision 64 (default: double Jacobi + double Horner, fp32 items in/out):
+  (a) projector        |P_hip - P_f64| <= 1e-7                       (LAPACK-fp32 oracle: ~4e-7)
+  (b) null spectrum    |Q_hip - Q_f64| <= 3e-7 Q + 2e-13 max Q  at EVERY angle, nulls included
+                       (LAPACK-fp32 oracle: up to 1e-2 relative at the nulls, ~1e-5 at 1e-2 max Q)
+  (c) vs the fp32 oracle: never further from it than it is from fp64, plus (b)
+  (d) dB spectrum      max is exactly 0 dB; |dB_hip - dB_f64| <= 2e-5 dB + 2e-6 |dB| on noisy data
+                       (on rank-deficient data the normaliser is itself a 1e-14-level quantity,
+                       so there the comparison is up to one common constant)
+  (e) arg-max bins (= angles through find_local_max) equal the fp64 oracle's: exactly on noisy
+      data, within one 180/P bin on rank-deficient data  (north_star: angles within 1e-3 deg).
+internal precision 32 (float Jacobi + float Horner): the same quantities within a small multiple
+of the LAPACK-fp32 oracle's own distance to fp64 (thresholds from the measured table).
 """
 import numpy as np
 import pytest
@@ -35,19 +39,20 @@ def _oracle_all(c, R):
     return (s32, q32, p32), (s64, q64, p64)
 
 
-@pytest.mark.parametrize("evd_bits", [64, 32])
+@pytest.mark.parametrize("bits", [64, 32])
 @pytest.mark.parametrize("name", MUSIC_CASES)
-def test_music_matches_oracle(name, evd_bits):
+def test_music_matches_oracle(name, bits):
     c, x = make_input(name)
     N, M, P, n = c["N"], c["M"], c["P"], c["n"]
     R = oracle.autocorrelate(x, c["K"], c["ovl"], c["fb"], n)            # identical inputs for both sides
     (s32, q32, p32), (s64, q64, p64) = _oracle_all(c, R)
+    deficient = is_rank_deficient(c)
 
-    doa.set_evd_precision(evd_bits)
+    doa.set_internal_precision(bits)
     try:
         blk = doa.MUSIC_lin_array(c["d"], M, N, P)
     finally:
-        doa.set_evd_precision(64)
+        doa.set_internal_precision(64)
     spec = np.empty((n, P), dtype=np.float32)
     assert blk.work(n, [R], [spec]) == n
     assert blk.nout_items_total() == n
@@ -55,38 +60,39 @@ def test_music_matches_oracle(name, evd_bits):
 
     for i in range(n):
         Ph = pn[i].reshape(N, N, order="F")
-        e_ref = np.abs(p32[i] - p64[i]).max()
-        e_hip = np.abs(Ph - p64[i]).max()
-        if evd_bits == 64:
-            assert e_hip <= 1e-6, (name, i, e_hip)                                   # (a)
-        else:
-            assert e_hip <= 4 * e_ref + 2e-6, (name, i, e_hip, e_ref)
-
         qt = q64[i]
-        good = qt >= 1e-2 * qt.max()
-        rel64 = np.abs(q[i] - qt)[good] / qt[good]
-        rel32 = np.abs(q[i] - q32[i])[good] / qt[good]
-        ref_rel = (np.abs(q32[i] - qt)[good] / qt[good]).max()
-        if evd_bits == 64:
-            assert rel64.max() <= 3e-6, (name, i, rel64.max())                       # (b)
-            assert rel32.max() <= max(1e-5, 1.5 * ref_rel + 3e-6), (name, i, rel32.max(), ref_rel)
+        mx = qt.max()
+        e_ref_p = np.abs(p32[i] - p64[i]).max()
+        e_hip_p = np.abs(Ph - p64[i]).max()
+        err = np.abs(q[i] - qt)
+        err_ref = np.abs(q32[i] - qt)
+        g1, g2 = qt >= 1e-1 * mx, qt >= 1e-2 * mx
+        if bits == 64:
+            assert e_hip_p <= 1e-7, (name, i, e_hip_p)                                          # (a)
+            assert np.all(err <= 3e-7 * np.abs(qt) + 2e-13 * mx), (name, i, (err / np.abs(qt)).max())   # (b)
+            assert np.all(np.abs(q[i] - q32[i]) <= err_ref + 3e-7 * np.abs(qt) + 2e-13 * mx)    # (c)
         else:
-            assert rel64.max() <= 4 * ref_rel + 3e-6, (name, i, rel64.max(), ref_rel)
-        ref_abs = np.abs(q32[i] - qt).max()
-        assert np.abs(q[i] - qt).max() <= 4 * ref_abs + 1e-6 * qt.max(), (name, i)   # (c)
+            assert e_hip_p <= 4 * e_ref_p + 1e-6, (name, i, e_hip_p, e_ref_p)
+            assert (err[g1] / qt[g1]).max() <= 6e-6, (name, i, (err[g1] / qt[g1]).max())
+            assert (err[g2] / qt[g2]).max() <= 4e-5, (name, i, (err[g2] / qt[g2]).max())
+            assert err.max() <= 4 * err_ref.max() + 1e-6 * mx, (name, i)
 
-        assert spec[i].max() == 0.0                                                  # (d)
-        diff = (spec[i].astype(np.float64) - s64[i])[good]
-        diff = diff[np.isfinite(diff)]
-        tol_db = 5e-5 if evd_bits == 64 else 4.35 * (4 * ref_rel + 3e-6) + 5e-5
-        assert diff.max() - diff.min() <= 2 * tol_db, (name, i, diff.max() - diff.min())
-
-        bins_ok = {int(np.argmax(s32[i])), int(np.argmax(s64[i]))}                   # (e)
-        got = int(np.argmax(spec[i]))
-        if is_rank_deficient(c):
-            assert min(abs(got - b) for b in bins_ok) <= 1, (name, i, got, bins_ok)
+        assert spec[i].max() == 0.0                                                             # (d)
+        fin = np.isfinite(s64[i])
+        diff = (spec[i].astype(np.float64) - s64[i])[fin]
+        if bits == 64 and not deficient:
+            assert np.all(np.abs(diff) <= 2e-5 + 2e-6 * np.abs(s64[i][fin])), (name, i, np.abs(diff).max())
         else:
-            assert got in bins_ok, (name, i, got, bins_ok)
+            dg = (spec[i].astype(np.float64) - s64[i])[g2 & fin]       # up to the normalisation constant
+            tol = 2e-5 if bits == 64 else 4e-4
+            assert dg.max() - dg.min() <= 2 * tol, (name, i, dg.max() - dg.min())
+
+        got = int(np.argmax(spec[i]))                                                           # (e)
+        want = {int(np.argmax(s64[i]))} if bits == 64 else {int(np.argmax(s64[i])), int(np.argmax(s32[i]))}
+        if deficient:
+            assert min(abs(got - b) for b in want) <= 1, (name, i, got, want)
+        else:
+            assert got in want, (name, i, got, want)
 
 
 @pytest.mark.parametrize("name", ["qa_music_aoa23", "qa_music_aoa121"])
