@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py — DoA snapshots/s through autocorrelate -> MUSIC_lin_array -> find_local_max on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1: launched under
+torch.distributed.run, one rank per GPU, RCCL only for the barrier / max-over-ranks).  Prints ONE
+JSON line from rank 0.
+
+Workload = BASELINE.json configs[1]: 4-element ULA, 1 source, 1024-sample snapshots (overlap 0),
+1024-point spectrum, batch = 4096 snapshots per step, complex fp32 streams resident in HBM,
+synthetic seeded data (doa.sim).  One step = one pass of the whole hot path over one batch:
+covariance (K1), Hermitian EVD + noise projector (K2+K3), spectrum scan (K4), peak pick (K5); the
+4 KiB spectrum of every snapshot is written out as the flowgraph does.  Steps rotate over several
+distinct input/output batches whose total footprint exceeds the 256 MiB Infinity Cache, so every
+step streams from HBM (a single 144 MiB working set would be served on-die).
+
+Multi-GPU (weak scaling): snapshots are independent, so every rank owns its own batch and there is
+no data-path collective; value = (steps * batch * world) / max-over-ranks time.
+"""
+import argparse
+import ctypes
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "gr-doa_amd", "python")]
+
+N_ANT, K_SNAP, P_SPEC, M_SRC, BATCH = 4, 1024, 1024, 1, 4096
+NORM_SPACING, SNR_DB = 0.5, 20.0
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+
+
+def algorithmic_bytes():
+    """Per snapshot, SURVEY §8(d): what each stage must read + write."""
+    cov = N_ANT * K_SNAP * 8 + N_ANT * N_ANT * 8           # K1: 32768 + 128
+    evd = N_ANT * N_ANT * 8 * 2                              # K2+K3: 128 + 128
+    scan = N_ANT * N_ANT * 8 + P_SPEC * 4                    # K4: 128 + 4096
+    peak = P_SPEC * 4 + 2 * M_SRC * 4                        # K5: 4096 + 8
+    return {"cov": cov, "evd": evd, "scan": scan, "peak": peak, "total": cov + evd + scan + peak}
+
+
+def cpu_baseline(budget_s=12.0):
+    """Times the C restatement of the reference path (oracle/doa_oracle.c, kind "port") on this
+    box's host cores over a bounded sample of the same workload.  When scipy's bundled OpenBLAS is
+    present the port calls the very BLAS/LAPACK routines Armadillo forwards to (cgemm, cheevd)."""
+    import numpy as np
+    so = os.path.join(ROOT, "oracle", "_build", "liboracle_doa.so")
+    if not os.path.exists(so):
+        return None
+    lib = ctypes.CDLL(so)
+    lapack = False
+    try:
+        import scipy
+        cands = glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas*.so"))
+        if cands and lib.oracle_use_lapack(cands[0].encode(), b"scipy_") == 0:
+            lapack = True
+    except Exception:
+        pass
+    from doa import sim
+    n_cal = 512
+    x, _ = sim.make_batch_streams(N_ANT, K_SNAP, n_cal, NORM_SPACING, M_SRC, SNR_DB, seed=7)
+
+    def run(xs, n, threads):
+        lib.oracle_set_num_threads(threads)
+        ptrs = (ctypes.c_void_p * N_ANT)(*[xs[k].ctypes.data for k in range(N_ANT)])
+        R = np.empty((n, N_ANT * N_ANT), np.complex64)
+        spec = np.empty((n, P_SPEC), np.float32)
+        mv = np.empty((n, M_SRC), np.float32)
+        am = np.empty((n, M_SRC), np.float32)
+        t0 = time.perf_counter()
+        rc = lib.oracle_music_pipeline(ptrs, N_ANT, K_SNAP, 0, 0, ctypes.c_float(NORM_SPACING), M_SRC, P_SPEC, n,
+                                       R.ctypes.data_as(ctypes.c_void_p), spec.ctypes.data_as(ctypes.c_void_p),
+                                       mv.ctypes.data_as(ctypes.c_void_p), am.ctypes.data_as(ctypes.c_void_p))
+        dt = time.perf_counter() - t0
+        assert rc == n, rc
+        return dt
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    # a one-GPU box owns a 16-thread share of its host; OpenBLAS's thread-buffer table is finite too
+    cores = max(1, min(cores, int(os.environ.get("DOA_CPU_THREADS", "16"))))
+    run(x, n_cal, cores)                                   # warm-up (page faults, OpenMP pool)
+    rate1 = n_cal / run(x, n_cal, 1)
+    rate_all_est = n_cal / run(x, n_cal, cores)
+    # bounded sample: ~budget_s of CPU work split between the single-thread and the all-core run
+    n_all = int(min(max(rate_all_est * budget_s * 0.6, n_cal), 65536))
+    reps = max(1, n_all // n_cal)
+    xs, _ = sim.make_batch_streams(N_ANT, K_SNAP, n_cal * min(reps, 16), NORM_SPACING, M_SRC, SNR_DB, seed=8)
+    n_run = xs.shape[1] // K_SNAP
+    times = sorted(run(xs, n_run, cores) for _ in range(max(3, reps // 16)))
+    rate_all = n_run / times[len(times) // 2]
+    n1 = int(min(max(rate1 * budget_s * 0.3, 128), n_run))
+    rate1 = n1 / run(xs[:, : n1 * K_SNAP].copy(), n1, 1)
+    return {"value": rate_all, "unit": "snapshots/s", "cores": cores, "kind": "port",
+            "sample": f"{n_run} snapshots x{len(times)} (median), same N=4/K=1024/P=1024 workload, all {cores} host "
+                      f"threads via OpenMP; eig/gemm = {'LAPACK cheevd + BLAS cgemm (scipy OpenBLAS)' if lapack else 'built-in Jacobi / loops'}",
+            "single_thread_value": rate1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
+                    help="internal precision of EVD + scan (items are fp32 either way)")
+    ap.add_argument("--nbuf", type=int, default=4, help="distinct batches rotated through (defeats L3 residency)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()))
+        return
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import doa
+    doa.set_internal_precision(args.precision)
+    pipe = doa.music_pipeline(N_ANT, K_SNAP, 0, 0, NORM_SPACING, M_SRC, P_SPEC, BATCH)
+    cov_blk = doa.autocorrelate(N_ANT, K_SNAP, 0, 0)
+    music_blk = doa.MUSIC_lin_array(NORM_SPACING, M_SRC, N_ANT, P_SPEC)
+    peak_blk = doa.find_local_max(M_SRC, P_SPEC, 0.0, 180.0)
+
+    # ---- synthetic, device-resident inputs (setup, not timed) -------------------------------------
+    nbuf = max(1, args.nbuf)
+    streams, thetas = [], []
+    for b in range(nbuf):
+        s, th = doa.sim.make_batch_streams_torch(N_ANT, K_SNAP, BATCH, NORM_SPACING, M_SRC, SNR_DB,
+                                                 seed=1000 * rank + b, device=f"cuda:{local_rank}")
+        streams.append(s)
+        thetas.append(th)
+    in_ptrs = [[t.data_ptr() for t in s] for s in streams]
+    spec = [torch.empty((BATCH, P_SPEC), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+    cov = [torch.empty((BATCH, N_ANT * N_ANT), dtype=torch.complex64, device="cuda") for _ in range(nbuf)]
+    mx = [torch.empty((BATCH, M_SRC), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+    am = [torch.empty((BATCH, M_SRC), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+    st = torch.cuda.current_stream()
+
+    def step(i):
+        b = i % nbuf
+        pipe.work_dev(BATCH, in_ptrs[b], cov[b].data_ptr(), spec[b].data_ptr(), mx[b].data_ptr(), am[b].data_ptr(), st)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the estimates of the last batch must sit on the directions they were generated with
+    import numpy as np
+    last = (args.steps - 1) % nbuf
+    est = am[last].cpu().numpy()[:, 0]
+    ang_err = float(np.abs(est - thetas[last][:, 0]).max())
+    if not ang_err <= 1.0:
+        raise SystemExit(f"bench sanity check failed: max angle error {ang_err} deg")
+
+    # ---- per-kernel timing with HIP events on the launch stream (after the timed region) -----------
+    def time_stage(fn, reps):
+        for i in range(5):
+            fn(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(st)
+        for i in range(reps):
+            fn(i)
+        e1.record(st)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps           # us per launch (includes the ~1.5 us launch gap)
+
+    reps = max(20, min(args.steps, 200))
+    t_cov = time_stage(lambda i: cov_blk.work_dev(BATCH, in_ptrs[i % nbuf], cov[i % nbuf].data_ptr(), st), reps)
+    t_music = time_stage(lambda i: music_blk.work_dev(BATCH, cov[i % nbuf].data_ptr(), spec[i % nbuf].data_ptr(), st), reps)
+    t_peak = time_stage(lambda i: peak_blk.work_dev(BATCH, spec[i % nbuf].data_ptr(), mx[i % nbuf].data_ptr(),
+                                                    am[i % nbuf].data_ptr(), st), reps)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ab = algorithmic_bytes()
+    total_snap = args.steps * BATCH * world
+    value = total_snap / elapsed
+    cov_gbs = ab["cov"] * BATCH / (t_cov * 1e-6) / 1e9
+    out = {
+        "metric": "DoA snapshots/sec (autocorr+MUSIC+peak) @ N=4, 1024 samp, 1024 angles",
+        "value": value,
+        "unit": "snapshots/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: 4-ch ULA, 1 source, K=1024 (overlap 0), P=1024, "
+                               "batch=4096 snapshots/step, complex fp32, SNR 20 dB",
+                   "batch": BATCH, "inputs": N_ANT, "snapshot_size": K_SNAP, "pspectrum_len": P_SPEC,
+                   "num_targets": M_SRC, "internal_precision": args.precision, "rotating_batches": nbuf,
+                   "parallelism": f"snapshot-sharded x{world}, no data-path collective"},
+        "pipeline_gbs": ab["total"] * value / world / 1e9,
+        "roofline": {"bound": "hbm", "kernel": "cov_wave_kernel<4,true> (K1 covariance)",
+                     "achieved": cov_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cov_gbs / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": ab["cov"] * BATCH, "avg_launch_us": t_cov},
+        "kernels": {
+            "K1_cov": {"us": t_cov, "GBs": cov_gbs},
+            "K2-K4_music(evd+scan)": {"us": t_music, "GBs": (ab["evd"] + ab["scan"]) * BATCH / (t_music * 1e-6) / 1e9},
+            "K5_peak": {"us": t_peak, "GBs": ab["peak"] * BATCH / (t_peak * 1e-6) / 1e9},
+        },
+        "max_angle_error_deg": ang_err,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        # in a child process: the CPU leg must never be able to take the GPU number down with it
+        import subprocess
+        try:
+            env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_DYNAMIC="FALSE")
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], env=env,
+                               capture_output=True, text=True, timeout=240)
+            out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
