@@ -13,6 +13,10 @@ covariance (K1), Hermitian EVD + noise projector (K2+K3), spectrum scan (K4), pe
 distinct input/output batches whose total footprint exceeds the 256 MiB Infinity Cache, so every
 step streams from HBM (a single 144 MiB working set would be served on-die).
 
+Steps alternate over a few HIP streams (default 4, one pipeline handle = one workspace per
+stream): each step's four launches stay in order on its own stream, while the HBM-bound covariance
+of one batch overlaps the latency-bound EVD / scan of the batches before it.
+
 Multi-GPU (weak scaling): snapshots are independent, so every rank owns its own batch and there is
 no data-path collective; value = (steps * batch * world) / max-over-ranks time.
 """
@@ -109,7 +113,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
                     help="internal precision of EVD + scan (items are fp32 either way)")
-    ap.add_argument("--nbuf", type=int, default=4, help="distinct batches rotated through (defeats L3 residency)")
+    ap.add_argument("--nbuf", type=int, default=6, help="distinct batches rotated through (defeats L3 residency)")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the steps alternate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -132,13 +137,15 @@ def main():
 
     import doa
     doa.set_internal_precision(args.precision)
-    pipe = doa.music_pipeline(N_ANT, K_SNAP, 0, 0, NORM_SPACING, M_SRC, P_SPEC, BATCH)
+    n_streams = max(1, args.streams)
+    pipes = [doa.music_pipeline(N_ANT, K_SNAP, 0, 0, NORM_SPACING, M_SRC, P_SPEC, BATCH) for _ in range(n_streams)]
+    hip_streams = [torch.cuda.Stream() for _ in range(n_streams)]
     cov_blk = doa.autocorrelate(N_ANT, K_SNAP, 0, 0)
     music_blk = doa.MUSIC_lin_array(NORM_SPACING, M_SRC, N_ANT, P_SPEC)
     peak_blk = doa.find_local_max(M_SRC, P_SPEC, 0.0, 180.0)
 
     # ---- synthetic, device-resident inputs (setup, not timed) -------------------------------------
-    nbuf = max(1, args.nbuf)
+    nbuf = max(n_streams + 1, args.nbuf)       # a buffer set is never reused while its step may be in flight
     streams, thetas = [], []
     for b in range(nbuf):
         s, th = doa.sim.make_batch_streams_torch(N_ANT, K_SNAP, BATCH, NORM_SPACING, M_SRC, SNR_DB,
@@ -153,8 +160,9 @@ def main():
     st = torch.cuda.current_stream()
 
     def step(i):
-        b = i % nbuf
-        pipe.work_dev(BATCH, in_ptrs[b], cov[b].data_ptr(), spec[b].data_ptr(), mx[b].data_ptr(), am[b].data_ptr(), st)
+        b, k = i % nbuf, i % n_streams
+        pipes[k].work_dev(BATCH, in_ptrs[b], cov[b].data_ptr(), spec[b].data_ptr(), mx[b].data_ptr(),
+                          am[b].data_ptr(), hip_streams[k])
 
     def barrier():
         torch.cuda.synchronize()
@@ -227,7 +235,7 @@ def main():
         "config": {"workload": "BASELINE.json configs[1]: 4-ch ULA, 1 source, K=1024 (overlap 0), P=1024, "
                                "batch=4096 snapshots/step, complex fp32, SNR 20 dB",
                    "batch": BATCH, "inputs": N_ANT, "snapshot_size": K_SNAP, "pspectrum_len": P_SPEC,
-                   "num_targets": M_SRC, "internal_precision": args.precision, "rotating_batches": nbuf,
+                   "num_targets": M_SRC, "internal_precision": args.precision, "rotating_batches": nbuf, "hip_streams": n_streams,
                    "parallelism": f"snapshot-sharded x{world}, no data-path collective"},
         "pipeline_gbs": ab["total"] * value / world / 1e9,
         "roofline": {"bound": "hbm", "kernel": "cov_wave_kernel<4,true> (K1 covariance)",

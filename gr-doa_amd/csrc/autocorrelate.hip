@@ -14,6 +14,8 @@
 // served by L2.  N > 8 runs as 8x8 channel tiles of the same loop.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace doa {
 
 struct CovArgs {
@@ -53,7 +55,7 @@ template <int TN> __device__ __forceinline__ void tri_accumulate(TriAcc<TN> &acc
 
 // One wave per snapshot, N = TN <= 8, Hermitian symmetry exploited.
 // VEC2: all streams 16-B aligned at every window start (base % 16 == 0, S even) -> float4 loads.
-template <int TN, bool VEC2>
+template <int TN, bool VEC2, int UN>
 __global__ __launch_bounds__(256) void cov_wave_kernel(CovArgs g)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -69,8 +71,27 @@ __global__ __launch_bounds__(256) void cov_wave_kernel(CovArgs g)
 
     if constexpr (VEC2) {
         const int npair = g.K >> 1;
-#pragma unroll 4
-        for (int p = lane; p < npair; p += kWave) {
+        // UN wave-iterations (UN*128 samples) per trip: all UN*TN 16-byte loads are issued before the
+        // first one is consumed, so each wave keeps UN*TN KiB in flight (HBM latency x bandwidth needs
+        // ~50 KiB per CU; 16 waves x 16 KiB gives 5x that while staying under 96 VGPRs).
+        int p = lane;
+        for (; p + (UN - 1) * kWave < npair; p += UN * kWave) {
+            float4 v[UN][TN];
+#pragma unroll
+            for (int u = 0; u < UN; u++)
+#pragma unroll
+                for (int a = 0; a < TN; a++)
+                    v[u][a] = *reinterpret_cast<const float4 *>(g.in[a] + base + 2 * (size_t)(p + u * kWave));
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                float2 x0[TN], x1[TN];
+#pragma unroll
+                for (int a = 0; a < TN; a++) { x0[a] = make_float2(v[u][a].x, v[u][a].y); x1[a] = make_float2(v[u][a].z, v[u][a].w); }
+                tri_accumulate<TN>(acc, x0);
+                tri_accumulate<TN>(acc, x1);
+            }
+        }
+        for (; p < npair; p += kWave) {
             float4 v[TN];
 #pragma unroll
             for (int a = 0; a < TN; a++) v[a] = *reinterpret_cast<const float4 *>(g.in[a] + base + 2 * (size_t)p);
@@ -230,14 +251,31 @@ __global__ void cov_fb_kernel(float2 *out, int nn, long long n_items, float fb_h
     if (e2 != e) p[e2] = nv;
 }
 
+// loads kept in flight per wave = UN*TN 16-byte loads; tuned on MI355X
+static int cov_unroll_override()
+{
+    static int v = [] { const char *e = getenv("DOA_COV_UN"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 template <int TN> static void launch_wave(const CovArgs &g, bool vec2, hipStream_t st)
 {
     const int waves_per_block = 4;
     dim3 grid((g.n_out + waves_per_block - 1) / waves_per_block), block(waves_per_block * kWave);
-    if (vec2)
-        hipLaunchKernelGGL((cov_wave_kernel<TN, true>), grid, block, 0, st, g);
-    else
-        hipLaunchKernelGGL((cov_wave_kernel<TN, false>), grid, block, 0, st, g);
+    constexpr int UN_DEF = (TN <= 4) ? 4 : ((TN <= 6) ? 2 : 1);
+    if (!vec2) {
+        hipLaunchKernelGGL((cov_wave_kernel<TN, false, 1>), grid, block, 0, st, g);
+        return;
+    }
+    if constexpr (TN == 4) {   // the benchmark shape: variants kept for A/B runs
+        switch (cov_unroll_override()) {
+        case 1: hipLaunchKernelGGL((cov_wave_kernel<TN, true, 1>), grid, block, 0, st, g); return;
+        case 2: hipLaunchKernelGGL((cov_wave_kernel<TN, true, 2>), grid, block, 0, st, g); return;
+        case 8: hipLaunchKernelGGL((cov_wave_kernel<TN, true, 8>), grid, block, 0, st, g); return;
+        default: break;
+        }
+    }
+    hipLaunchKernelGGL((cov_wave_kernel<TN, true, UN_DEF>), grid, block, 0, st, g);
 }
 
 // Launches K1 on `st`.  d_in: N device pointers.  Returns DOA_OK / error.

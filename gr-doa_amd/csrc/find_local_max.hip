@@ -17,8 +17,8 @@
 // the top-M are M rounds of a wave arg-max.  Vector lengths that are not a multiple of 4 or exceed
 // 4096 take a one-thread-per-vector fallback that walks the reference's steps literally.
 #include "kernels.hpp"
+#include "peak_device.hpp"
 
-#include <climits>
 #include <vector>
 
 namespace doa {
@@ -39,30 +39,6 @@ int PeakTables::build(int num_max_vals, int vector_len, float x_min_, float x_ma
     if (rc != DOA_OK) return rc;
     DOA_HIP_TRY(hipMemcpy(d_x.p, x.data(), sizeof(float) * (size_t)L, hipMemcpyHostToDevice));
     return DOA_OK;
-}
-
-// (value, index) ordering used for ranking: larger value first, then lower index; idx == INT_MAX
-// marks "no candidate".
-__device__ __forceinline__ bool cand_better(float v, int i, float bv, int bi)
-{
-    if (i == INT_MAX) return false;
-    if (bi == INT_MAX) return true;
-    return (v > bv) || (v == bv && i < bi);
-}
-__device__ __forceinline__ void wave_argbest(float &v, int &i)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float ov = __shfl_xor(v, m, kWave);
-        const int oi = __shfl_xor(i, m, kWave);
-        if (cand_better(ov, oi, v, i)) { v = ov; i = oi; }
-    }
-}
-__device__ __forceinline__ int wave_sum_int(int x)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, kWave);
-    return x;
 }
 
 template <int CH>
@@ -86,135 +62,7 @@ __global__ __launch_bounds__(256) void find_local_max_kernel(const float *__rest
             v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
         }
     }
-
-    int sel_idx = INT_MAX;      // lane r keeps the r-th ranked index
-    float sel_val = 0.f;
-    int n_valid = 0, best_list_pos = 0;
-
-    if (M > 1) {
-        // --- sign of the first-order difference; positions past the last difference act as +1 ---
-        int s[CH][4];
-        bool flat_here = false;
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            float nxt_first = __shfl_down(v[j][0], 1, kWave);                 // lane+1, e=0, same chunk
-            const float wrap = (j + 1 < CH) ? __shfl(v[(j + 1 < CH) ? j + 1 : j][0], 0, kWave) : 0.f;
-            if (lane == kWave - 1) nxt_first = wrap;                          // lane 0 of the next chunk
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int p = 256 * j + 4 * lane + e;
-                const float nx = (e < 3) ? v[j][e + 1] : nxt_first;
-                if (p < L - 1) {
-                    const float d = nx - v[j][e];
-                    s[j][e] = (d > 0.f) ? 1 : ((d < 0.f) ? -1 : 0);
-                    flat_here |= (s[j][e] == 0);
-                } else {
-                    s[j][e] = 1;
-                }
-            }
-        }
-        // --- flats: suffix scan in position order (chunk, lane, e), last chunk first ---
-        if (__any(flat_here)) {
-            int chunk_carry = 1;  // sign taken by a flat that runs to the end of the vector
-#pragma unroll
-            for (int j = CH - 1; j >= 0; j--) {
-                int f = 0;
-#pragma unroll
-                for (int e = 3; e >= 0; e--) f = (s[j][e] != 0) ? s[j][e] : f;   // first non-zero of this lane
-                const unsigned long long nz = __ballot(f != 0), pos = __ballot(f > 0);
-                const unsigned long long above = (lane == kWave - 1) ? 0ull : (nz >> (lane + 1));
-                int carry = chunk_carry;
-                if (above) {
-                    const int src = lane + 1 + __builtin_ctzll(above);
-                    carry = ((pos >> src) & 1ull) ? 1 : -1;
-                }
-#pragma unroll
-                for (int e = 3; e >= 0; e--) {
-                    if (s[j][e] == 0) s[j][e] = carry;
-                    carry = s[j][e];
-                }
-                chunk_carry = __shfl(s[j][0], 0, kWave);
-            }
-        }
-        // --- peaks: s[p-1] == +1 and s[p] == -1 ---
-        unsigned long long pk = 0;   // bit (4*j+e)
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            int prev_last = __shfl_up(s[j][3], 1, kWave);                      // lane-1, e=3
-            const int wrap = (j > 0) ? __shfl(s[(j > 0) ? j - 1 : 0][3], kWave - 1, kWave) : 0;
-            if (lane == 0) prev_last = wrap;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int p = 256 * j + 4 * lane + e;
-                const int sp = (e > 0) ? s[j][e - 1] : prev_last;
-                if (p >= 1 && p <= L - 2 && sp == 1 && s[j][e] == -1) pk |= 1ull << (4 * j + e);
-            }
-        }
-        n_valid = wave_sum_int(__popcll(pk));
-        // --- top-M by value (descending), ties -> lowest index ---
-        const int rounds = (n_valid < M) ? n_valid : M;
-        for (int r = 0; r < rounds; r++) {
-            float bv = 0.f;
-            int bi = INT_MAX;
-#pragma unroll
-            for (int j = 0; j < CH; j++)
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if ((pk >> (4 * j + e)) & 1ull) {
-                        const int p = 256 * j + 4 * lane + e;
-                        if (cand_better(v[j][e], p, bv, bi)) { bv = v[j][e]; bi = p; }
-                    }
-            wave_argbest(bv, bi);
-            if (r == 0) {
-                // position of the best peak inside the ascending peak list (= #peaks before it)
-                int before = 0;
-#pragma unroll
-                for (int j = 0; j < CH; j++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (((pk >> (4 * j + e)) & 1ull) && (256 * j + 4 * lane + e) < bi) before++;
-                best_list_pos = wave_sum_int(before);
-            }
-            // owner drops the winner from its candidate set
-            if (bi != INT_MAX && ((bi & 255) >> 2) == lane) pk &= ~(1ull << (4 * (bi >> 8) + (bi & 3)));
-            if (lane == r) { sel_idx = bi; sel_val = bv; }
-        }
-    }
-
-    // --- fill slots / M == 1: indices that are not ranked peaks ---
-    int fill_idx = 0;
-    if (M == 1 || n_valid == 0) {
-        // arma index_max (op_max::direct_max): best starts at -inf, an element replaces it only if
-        // strictly greater -> first occurrence of the maximum, NaNs never win, nothing > -inf -> 0
-        float bv = 0.f;
-        int bi = INT_MAX;
-#pragma unroll
-        for (int j = 0; j < CH; j++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int p = 256 * j + 4 * lane + e;
-                if (p < L && v[j][e] > -INFINITY && cand_better(v[j][e], p, bv, bi)) { bv = v[j][e]; bi = p; }
-            }
-        wave_argbest(bv, bi);
-        fill_idx = (bi == INT_MAX) ? 0 : bi;
-    } else {
-        fill_idx = best_list_pos;   // reference quirk: list position used as a vector index (:153,160)
-    }
-    if (lane < M) {
-        int idx;
-        float val;
-        if (M > 1 && lane < n_valid) { idx = sel_idx; val = sel_val; }
-        else { idx = fill_idx; val = v_in[fill_idx]; }
-        const float x = xaxis[idx];
-        out_val[(size_t)item * M + lane] = val;
-        // descending sort of the M locations: rank = number of entries that must precede this one
-        int rank = 0;
-        for (int k = 0; k < M; k++) {
-            const float xk = __shfl(x, k, kWave);
-            rank += (xk > x || (xk == x && k < lane)) ? 1 : 0;
-        }
-        out_loc[(size_t)item * M + rank] = x;
-    }
+    peak_pick<CH>(v, lane, L, M, xaxis, out_val + (size_t)item * M, out_loc + (size_t)item * M);
 }
 
 // Literal walk of the reference's steps, one thread per vector (any L >= 1).  `scratch` holds L

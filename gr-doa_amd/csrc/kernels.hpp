@@ -28,8 +28,12 @@ int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, v
                      int evd_bits, hipStream_t st);
 // K4: spectrum scan in float (bits == 32, float coefficient records) or double (bits == 64, double
 // records).  d_q (un-normalised null spectrum, P floats per item) may be NULL.
+// With `peaks` (+ d_max/d_argmax) the find_local_max step is fused into the scan when the fast path
+// applies; *peaks_done tells the caller whether it still has to launch K5 itself.
+struct PeakTables;
 int launch_music_scan(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec, void *d_q,
-                      hipStream_t st);
+                      hipStream_t st, const PeakTables *peaks = nullptr, void *d_max = nullptr,
+                      void *d_argmax = nullptr, bool *peaks_done = nullptr);
 
 // K5 (find_local_max.hip)
 struct PeakTables {

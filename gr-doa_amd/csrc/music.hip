@@ -23,6 +23,7 @@
 //     items), the item maximum is a wave all-reduce, and each store instruction writes 1 KiB
 //     contiguous.  Values match the reference's a^H P a up to fp32 rounding (~1e-7 relative).
 #include "kernels.hpp"
+#include "peak_device.hpp"
 
 #include <cmath>
 #include <vector>
@@ -89,68 +90,80 @@ template <> struct Real<double> {
         e = fma(-x * y, y, 1.0);
         return fma(0.5 * y, e, y);
     }
-    static constexpr double tol = 2e-31;
+    static constexpr double tol = 1e-27;     // off-norm/diag-norm <= 3e-14: eigenvectors good to ~1e-13
     static constexpr double tiny = 1e-290;
     static constexpr double tau_max = 1e140;
     static constexpr int max_sweeps = 14;
 };
 
-// A (Hermitian, full storage) and V live in ar/ai/vr/vi; on return A is diagonal to working
-// precision and the columns of V are the eigenvectors.
+// Cyclic complex Jacobi on a Hermitian matrix kept as its real diagonal dg[] and strict upper
+// triangle (ur, ui)[r][c], r < c (the lower triangle is never formed: A[c][r] = conj(A[r][c])).
+// On return dg holds the eigenvalues and the columns of V = (vr, vi) the eigenvectors.
+// One rotation (p,q): J[p][p] = J[q][q] = c, J[p][q] = sigma = s e^{j phi}, J[q][p] = -conj(sigma)
+// with phi = arg A[p][q] and t = s/c the smaller root of t^2 + 2 tau t - 1 = 0,
+// tau = (A[q][q]-A[p][p]) / (2|A[p][q]|).  c, s and e^{j phi} are built from rsqrt only, so J is
+// unitary to working precision and no division appears.  A <- J^H A J touches, for every k not in
+// {p,q}, the pair (A[k][p], A[k][q]) and the two diagonal entries; V <- V J touches columns p, q.
 template <int N, typename T, bool UNROLL>
-__device__ __forceinline__ void herm_jacobi(T (&ar)[N][N], T (&ai)[N][N], T (&vr)[N][N], T (&vi)[N][N])
+__device__ __forceinline__ void herm_jacobi(T (&dg)[N], T (&ur)[N][N], T (&ui)[N][N], T (&vr)[N][N], T (&vi)[N][N])
 {
     constexpr int U = UNROLL ? N : 1;
     const int max_sweeps = (N <= 4) ? Real<T>::max_sweeps : Real<T>::max_sweeps + 2 * N;
     for (int sweep = 0; sweep < max_sweeps; sweep++) {
-        T off = 0, dg = 0;
+        T off = 0, dn = 0;
 #pragma unroll U
         for (int p = 0; p < N; p++) {
-            dg = fma(ar[p][p], ar[p][p], dg);
+            dn = fma(dg[p], dg[p], dn);
 #pragma unroll U
             for (int q = 0; q < N; q++)
-                if (q > p) off += ar[p][q] * ar[p][q] + ai[p][q] * ai[p][q];
+                if (q > p) off += ur[p][q] * ur[p][q] + ui[p][q] * ui[p][q];
         }
-        if (!(off > Real<T>::tol * dg) || !(off > Real<T>::tiny)) break;
+        if (!(off > Real<T>::tol * dn) || !(off > Real<T>::tiny)) break;
 #pragma unroll U
         for (int p = 0; p < N - 1; p++) {
 #pragma unroll U
             for (int q = 1; q < N; q++) {
                 if (q <= p) continue;
-                const T apr = ar[p][q], api = ai[p][q];
+                const T apr = ur[p][q], api = ui[p][q];
                 const T g2 = apr * apr + api * api;
-                if (!(g2 > Real<T>::tiny)) continue;
-                const T inv_g = Real<T>::rsqrt(g2);
+                // branch-free: a pivot that is already (numerically) zero gets the identity rotation
+                const bool live = g2 > Real<T>::tiny;
+                const T inv_g = Real<T>::rsqrt(live ? g2 : (T)1);
+                const T g = live ? g2 * inv_g : (T)0;
                 const T phr = apr * inv_g, phi = api * inv_g;          // e^{j phi}
-                T tau = (ar[q][q] - ar[p][p]) * (T)0.5 * inv_g;
+                T tau = (dg[q] - dg[p]) * (T)0.5 * inv_g;
                 tau = fmin(fmax(tau, -Real<T>::tau_max), Real<T>::tau_max);
                 const T x1 = fma(tau, tau, (T)1);
                 const T r = x1 * Real<T>::rsqrt(x1);                    // sqrt(1+tau^2)
                 const T h = fabs(tau) + r;                              // 1/|t|
                 const T w = Real<T>::rsqrt(fma(h, h, (T)1));
-                const T c = h * w;
-                const T s = copysign(w, tau);
-                const T spr = s * phr, spi = s * phi;                   // J[p][q] = s e^{j phi}
-                // columns p,q:  A <- A J      (J[p][p]=J[q][q]=c, J[q][p] = -conj(J[p][q]))
+                const T c = live ? h * w : (T)1;
+                const T s = live ? copysign(w, tau) : (T)0;
+                const T spr = s * phr, spi = s * phi;                   // sigma
+                // 2x2 block: a_pp' = c^2 a_pp - 2cs g + s^2 a_qq,  a_qq' = s^2 a_pp + 2cs g + c^2 a_qq,  a_pq' = 0
+                {
+                    const T cc = c * c, ss = s * s, csg = (T)2 * c * s * g;
+                    const T app = dg[p], aqq = dg[q];
+                    dg[p] = fma(cc, app, fma(ss, aqq, -csg));
+                    dg[q] = fma(ss, app, fma(cc, aqq, csg));
+                    ur[p][q] = 0; ui[p][q] = 0;
+                }
+                // off-diagonal pairs (A[k][p], A[k][q]), k not in {p,q}:
+                //   x' = c x - conj(sigma) y,   y' = sigma x + c y
 #pragma unroll U
                 for (int k = 0; k < N; k++) {
-                    const T kpr = ar[k][p], kpi = ai[k][p], kqr = ar[k][q], kqi = ai[k][q];
-                    ar[k][p] = c * kpr - (spr * kqr + spi * kqi);
-                    ai[k][p] = c * kpi - (spr * kqi - spi * kqr);
-                    ar[k][q] = c * kqr + (spr * kpr - spi * kpi);
-                    ai[k][q] = c * kqi + (spr * kpi + spi * kpr);
+                    if (k == p || k == q) continue;
+                    // A[k][p] lives at (k,p) if k < p, else as the conjugate of (p,k); same for q
+                    T xr, xi, yr, yi;
+                    if (k < p) { xr = ur[k][p]; xi = ui[k][p]; } else { xr = ur[p][k]; xi = -ui[p][k]; }
+                    if (k < q) { yr = ur[k][q]; yi = ui[k][q]; } else { yr = ur[q][k]; yi = -ui[q][k]; }
+                    const T nxr = c * xr - (spr * yr + spi * yi);
+                    const T nxi = c * xi - (spr * yi - spi * yr);
+                    const T nyr = c * yr + (spr * xr - spi * xi);
+                    const T nyi = c * yi + (spr * xi + spi * xr);
+                    if (k < p) { ur[k][p] = nxr; ui[k][p] = nxi; } else { ur[p][k] = nxr; ui[p][k] = -nxi; }
+                    if (k < q) { ur[k][q] = nyr; ui[k][q] = nyi; } else { ur[q][k] = nyr; ui[q][k] = -nyi; }
                 }
-                // rows p,q:  A <- J^H A
-#pragma unroll U
-                for (int k = 0; k < N; k++) {
-                    const T pkr = ar[p][k], pki = ai[p][k], qkr = ar[q][k], qki = ai[q][k];
-                    ar[p][k] = c * pkr - (spr * qkr - spi * qki);
-                    ai[p][k] = c * pki - (spr * qki + spi * qkr);
-                    ar[q][k] = c * qkr + (spr * pkr + spi * pki);
-                    ai[q][k] = c * qki + (spr * pki - spi * pkr);
-                }
-                ar[p][q] = 0; ai[p][q] = 0; ar[q][p] = 0; ai[q][p] = 0;
-                ai[p][p] = 0; ai[q][q] = 0;
                 // V <- V J
 #pragma unroll U
                 for (int k = 0; k < N; k++) {
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict_
     if (item >= n_items) return;
     const float2 *Ri = R + (size_t)item * (N * N);
 
-    T ar[N][N], ai[N][N], vr[N][N], vi[N][N];
+    T dg[N], ar[N][N], ai[N][N], vr[N][N], vi[N][N];
     // only the upper triangle of the item is significant (cheevd uplo='U'); element (r,c) at r + c*N
 #pragma unroll U
     for (int c = 0; c < N; c++) {
@@ -184,8 +197,8 @@ __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict_
         for (int r = 0; r < N; r++) {
             if (r > c) continue;
             const float2 x = Ri[r + c * N];
-            if (r == c) { ar[r][c] = (T)x.x; ai[r][c] = 0; }
-            else { ar[r][c] = (T)x.x; ai[r][c] = (T)x.y; ar[c][r] = (T)x.x; ai[c][r] = -(T)x.y; }
+            if (r == c) dg[r] = (T)x.x;
+            else { ar[r][c] = (T)x.x; ai[r][c] = (T)x.y; }
         }
     }
 #pragma unroll U
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict_
 #pragma unroll U
         for (int c = 0; c < N; c++) { vr[r][c] = (r == c) ? (T)1 : (T)0; vi[r][c] = 0; }
 
-    herm_jacobi<N, T, UNROLL>(ar, ai, vr, vi);
+    herm_jacobi<N, T, UNROLL>(dg, ar, ai, vr, vi);
 
     // ascending rank of each eigenvalue (eig_sym contract); noise set = ranks < N-M
     T sel[N];
@@ -202,23 +215,31 @@ __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict_
         int rank = 0;
 #pragma unroll U
         for (int j = 0; j < N; j++) {
-            const bool before = (ar[j][j] < ar[i][i]) || (ar[j][j] == ar[i][i] && j < i);
+            const bool before = (dg[j] < dg[i]) || (dg[j] == dg[i] && j < i);
             rank += before ? 1 : 0;
         }
         sel[i] = (rank < N - M) ? (T)1 : (T)0;
     }
-    // P_N[a][b] = sum_i sel_i v[a][i] conj(v[b][i]); reuse ar/ai for P_N
+    // P_N[a][b] = sum_i sel_i v[a][i] conj(v[b][i]), Hermitian: upper triangle + diagonal only
+    // (reusing dg / ar / ai for P_N)
+    T svr[N][N], svi[N][N];
+#pragma unroll U
+    for (int a = 0; a < N; a++)
+#pragma unroll U
+        for (int i = 0; i < N; i++) { svr[a][i] = sel[i] * vr[a][i]; svi[a][i] = sel[i] * vi[a][i]; }
 #pragma unroll U
     for (int a = 0; a < N; a++) {
 #pragma unroll U
         for (int b = 0; b < N; b++) {
+            if (b < a) continue;
             T pr = 0, pi = 0;
 #pragma unroll U
             for (int i = 0; i < N; i++) {
-                pr += sel[i] * (vr[a][i] * vr[b][i] + vi[a][i] * vi[b][i]);
-                pi += sel[i] * (vi[a][i] * vr[b][i] - vr[a][i] * vi[b][i]);
+                pr = fma(svr[a][i], vr[b][i], fma(svi[a][i], vi[b][i], pr));
+                pi = fma(svi[a][i], vr[b][i], fma(-svr[a][i], vi[b][i], pi));
             }
-            ar[a][b] = pr; ai[a][b] = pi;
+            if (a == b) dg[a] = pr;
+            else { ar[a][b] = pr; ai[a][b] = pi; }
         }
     }
     if (pn_out) {
@@ -226,24 +247,34 @@ __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict_
 #pragma unroll U
         for (int c = 0; c < N; c++)
 #pragma unroll U
-            for (int r = 0; r < N; r++) po[r + c * N] = make_float2((float)ar[r][c], (float)ai[r][c]);
+            for (int r = 0; r < N; r++) {
+                float2 e;
+                if (r == c) e = make_float2((float)dg[r], 0.f);
+                else if (r < c) e = make_float2((float)ar[r][c], (float)ai[r][c]);
+                else e = make_float2((float)ar[c][r], -(float)ai[c][r]);
+                po[r + c * N] = e;
+            }
     }
-    // diagonal sums u_l = sum_r P_N[r+l][r]; float record for the scan, double record for the root
-    // finder (Root-MUSIC's near-double roots amplify a float rounding of u_l by ~1e3-1e4)
+    // diagonal sums u_l = sum_r P_N[r+l][r] = conj(sum_r P_N[r][r+l]); float record for the scan, double
+    // record for the root finder (Root-MUSIC's near-double roots amplify a float rounding of u_l by
+    // ~1e3-1e4) and for the double scan
     float *co = coef ? coef + (size_t)item * (2 * N) : nullptr;
     double *cd = coef_d ? coef_d + (size_t)item * (2 * N) : nullptr;
 #pragma unroll U
     for (int l = 0; l < N; l++) {
-        T ur = 0, ui = 0;
+        T ur_ = 0, ui_ = 0;
 #pragma unroll U
         for (int r = 0; r < N; r++)
-            if (r + l < N) { ur += ar[r + l][r]; ui += ai[r + l][r]; }
+            if (r + l < N) {
+                if (l == 0) ur_ += dg[r];
+                else { ur_ += ar[r][r + l]; ui_ -= ai[r][r + l]; }
+            }
         if (l == 0) {
-            if (co) co[0] = (float)ur;
-            if (cd) cd[0] = (double)ur;
+            if (co) co[0] = (float)ur_;
+            if (cd) cd[0] = (double)ur_;
         } else {
-            if (co) { co[2 * l - 1] = (float)ur; co[2 * l] = (float)ui; }
-            if (cd) { cd[2 * l - 1] = (double)ur; cd[2 * l] = (double)ui; }
+            if (co) { co[2 * l - 1] = (float)ur_; co[2 * l] = (float)ui_; }
+            if (cd) { cd[2 * l - 1] = (double)ur_; cd[2 * l] = (double)ui_; }
         }
     }
     if (co) co[2 * N - 1] = 0.f;
@@ -304,16 +335,20 @@ __device__ __forceinline__ float db_from_ratio(float out, float mx, float inv_mx
     // 10*log10(out/max).  The maximum itself must come out as exactly 0 dB (x/x == 1 in the
     // reference; inf/inf stays NaN as there), everything else is out*(1/max) through the hardware
     // log2: 10*log10(r) = (10*log10(2)) * log2(r).
-    float ratio = (out == mx && mx != INFINITY) ? 1.0f : out * inv_mx;
+    // out <= max, so out/max <= 1 in the reference; the reciprocal multiply is clamped to keep that
+    float ratio = (out == mx && mx != INFINITY) ? 1.0f : fminf(out * inv_mx, 1.0f);
     return 3.0102999566398120f * __log2f(ratio);
 }
 
 // Fast path: P % 4 == 0 and P <= 256*CH.  One wave per item, grid-stride over items so that the
-// z table (4*CH angles per lane) is loaded once per wave and stays in registers.
-template <int N, int CH, typename T>
+// z table (4*CH angles per lane) is loaded once per wave and stays in registers.  With PEAK the
+// find_local_max step (K5) runs on the dB values while they are still in registers, so the spectrum
+// is written once and never read back.
+template <int N, int CH, typename T, bool HAS_Q, bool PEAK>
 __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                          float *__restrict__ spec, float *__restrict__ qout, int P,
-                                                         int n_items)
+                                                         int n_items, const float *__restrict__ xaxis,
+                                                         float *__restrict__ pk_val, float *__restrict__ pk_loc, int M)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
@@ -342,9 +377,11 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const float q = (float)null_spectrum<N, T>(c, zr[j][e], zi[j][e]);
-                if (qout && live) qout[(size_t)item * P + 4 * lane + 256 * j + e] = q;
+                if constexpr (HAS_Q) {
+                    if (live) qout[(size_t)item * P + 4 * lane + 256 * j + e] = q;
+                }
                 out[j][e] = __builtin_amdgcn_rcpf(q);           // 1.0/Q  (:140)
-                if (live) mx = fmaxf(mx, out[j][e]);
+                mx = live ? fmaxf(mx, out[j][e]) : mx;
             }
         }
         mx = wave_allreduce_max(mx);
@@ -353,15 +390,11 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
 #pragma unroll
         for (int j = 0; j < CH; j++) {
             const int i0 = 4 * lane + 256 * j;
-            if (i0 < P) {
-                float4 v;
-                v.x = db_from_ratio(out[j][0], mx, inv_mx);
-                v.y = db_from_ratio(out[j][1], mx, inv_mx);
-                v.z = db_from_ratio(out[j][2], mx, inv_mx);
-                v.w = db_from_ratio(out[j][3], mx, inv_mx);
-                *reinterpret_cast<float4 *>(row + i0) = v;
-            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) out[j][e] = db_from_ratio(out[j][e], mx, inv_mx);   // now dB
+            if (i0 < P) *reinterpret_cast<float4 *>(row + i0) = make_float4(out[j][0], out[j][1], out[j][2], out[j][3]);
         }
+        if constexpr (PEAK) peak_pick<CH>(out, lane, P, M, xaxis, pk_val + (size_t)item * M, pk_loc + (size_t)item * M);
     }
 }
 
@@ -394,8 +427,31 @@ __global__ __launch_bounds__(256) void music_scan_generic_kernel(const T *__rest
     }
 }
 
+struct ScanPeakArgs {           // optional fused K5
+    const float *xaxis = nullptr;
+    float *val = nullptr, *loc = nullptr;
+    int M = 0;
+};
+
+template <int N, int CH, typename T>
+static void launch_scan_fast(dim3 grid, dim3 block, hipStream_t st, const T *co, const T *z, float *sp, float *q, int P,
+                             int n_items, const ScanPeakArgs &pk)
+{
+    if (q)
+        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, true, false>), grid, block, 0, st, co, z, sp, q, P, n_items,
+                           nullptr, nullptr, nullptr, 0);
+    else if (pk.val)
+        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, true>), grid, block, 0, st, co, z, sp, q, P, n_items,
+                           pk.xaxis, pk.val, pk.loc, pk.M);
+    else
+        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, false>), grid, block, 0, st, co, z, sp, q, P, n_items,
+                           nullptr, nullptr, nullptr, 0);
+}
+
+// returns true when the fused peak pick ran (fast path only)
 template <int N, typename T>
-static void launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_spec, void *d_q, hipStream_t st)
+static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_spec, void *d_q, const ScanPeakArgs &pk,
+                           hipStream_t st)
 {
     float *sp = (float *)d_spec, *q = (float *)d_q;
     const int waves_per_block = 4;
@@ -406,35 +462,41 @@ static void launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
     const int max_blocks = 256 * 8;
     if (blocks > max_blocks) blocks = max_blocks;
     dim3 grid(blocks), block(waves_per_block * kWave);
-    if (aligned && P <= 256)
-        hipLaunchKernelGGL((music_scan_kernel<N, 1, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
-    else if (aligned && P <= 512)
-        hipLaunchKernelGGL((music_scan_kernel<N, 2, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
-    else if (aligned && P <= 1024)
-        hipLaunchKernelGGL((music_scan_kernel<N, 4, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
-    else if (aligned && P <= 2048 && sizeof(T) == 4)
-        hipLaunchKernelGGL((music_scan_kernel<N, 8, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
-    else if (aligned && P <= 4096 && sizeof(T) == 4)
-        hipLaunchKernelGGL((music_scan_kernel<N, 16, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
-    else
-        hipLaunchKernelGGL((music_scan_generic_kernel<N, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
+    const int max_ch = (sizeof(T) == 4) ? 16 : 4;        // double z table: 4 chunks fit the register file
+    if (aligned && P <= 256 * max_ch) {
+        if (P <= 256) launch_scan_fast<N, 1, T>(grid, block, st, co, z, sp, q, P, n_items, pk);
+        else if (P <= 512) launch_scan_fast<N, 2, T>(grid, block, st, co, z, sp, q, P, n_items, pk);
+        else if (P <= 1024) launch_scan_fast<N, 4, T>(grid, block, st, co, z, sp, q, P, n_items, pk);
+        else if constexpr (sizeof(T) == 4) {
+            if (P <= 2048) launch_scan_fast<N, 8, T>(grid, block, st, co, z, sp, q, P, n_items, pk);
+            else launch_scan_fast<N, 16, T>(grid, block, st, co, z, sp, q, P, n_items, pk);
+        }
+        return pk.val != nullptr && q == nullptr;
+    }
+    hipLaunchKernelGGL((music_scan_generic_kernel<N, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
+    return false;
 }
 
-template <int N> static void launch_scan_n(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec,
-                                           void *d_q, hipStream_t st)
+template <int N> static bool launch_scan_n(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec,
+                                           void *d_q, const ScanPeakArgs &pk, hipStream_t st)
 {
     if (bits == 32)
-        launch_scan_nt<N, float>((const float *)d_coef, t.d_z.as<float>(), t.P, n_items, d_spec, d_q, st);
-    else
-        launch_scan_nt<N, double>((const double *)d_coef, t.d_zd.as<double>(), t.P, n_items, d_spec, d_q, st);
+        return launch_scan_nt<N, float>((const float *)d_coef, t.d_z.as<float>(), t.P, n_items, d_spec, d_q, pk, st);
+    return launch_scan_nt<N, double>((const double *)d_coef, t.d_zd.as<double>(), t.P, n_items, d_spec, d_q, pk, st);
 }
 
 int launch_music_scan(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec, void *d_q,
-                      hipStream_t st)
+                      hipStream_t st, const PeakTables *peaks, void *d_max, void *d_argmax, bool *peaks_done)
 {
+    if (peaks_done) *peaks_done = false;
     if (n_items <= 0) return DOA_OK;
+    ScanPeakArgs pk;
+    if (peaks && d_max && d_argmax && peaks->L == t.P) {
+        pk.xaxis = peaks->d_x.as<float>(); pk.val = (float *)d_max; pk.loc = (float *)d_argmax; pk.M = peaks->M;
+    }
+    bool done = false;
     switch (t.N) {
-#define DOA_SCAN_CASE(n) case n: launch_scan_n<n>(t, bits, n_items, d_coef, d_spec, d_q, st); break;
+#define DOA_SCAN_CASE(n) case n: done = launch_scan_n<n>(t, bits, n_items, d_coef, d_spec, d_q, pk, st); break;
         DOA_SCAN_CASE(2) DOA_SCAN_CASE(3) DOA_SCAN_CASE(4) DOA_SCAN_CASE(5) DOA_SCAN_CASE(6) DOA_SCAN_CASE(7)
         DOA_SCAN_CASE(8) DOA_SCAN_CASE(9) DOA_SCAN_CASE(10) DOA_SCAN_CASE(11) DOA_SCAN_CASE(12) DOA_SCAN_CASE(13)
         DOA_SCAN_CASE(14) DOA_SCAN_CASE(15) DOA_SCAN_CASE(16)
@@ -443,6 +505,7 @@ int launch_music_scan(const MusicTables &t, int bits, int n_items, const void *d
         set_error("MUSIC: num_ant_ele=%d outside the built range 2..%d", t.N, DOA_MAX_ANT_ELE);
         return DOA_ERR_UNSUPPORTED;
     }
+    if (peaks_done) *peaks_done = done;
     DOA_HIP_TRY(hipGetLastError());
     return DOA_OK;
 }

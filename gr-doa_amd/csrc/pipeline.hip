@@ -94,8 +94,11 @@ int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput_items, cons
     rc = doa::launch_music_evd(h->N, h->music.M, noutput_items, cov, dbl ? nullptr : h->d_coef.p,
                                dbl ? h->d_coef.p : nullptr, nullptr, h->bits, st);
     if (rc != DOA_OK) return rc;
-    rc = doa::launch_music_scan(h->music, h->bits, noutput_items, h->d_coef.p, spec, nullptr, st);
+    bool peaks_done = false;
+    rc = doa::launch_music_scan(h->music, h->bits, noutput_items, h->d_coef.p, spec, nullptr, st, &h->peaks, d_max_out,
+                                d_argmax_out, &peaks_done);
     if (rc != DOA_OK) return rc;
+    if (peaks_done) return noutput_items;
     if (doa::find_local_max_fast_ok(h->peaks.L, spec)) {
         rc = doa::launch_find_local_max(h->peaks, noutput_items, spec, d_max_out, d_argmax_out, st);
     } else {

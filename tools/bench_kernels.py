@@ -1,0 +1,80 @@
+"""GPU micro-benchmark of the individual stages (not part of the graded bench): HIP-event timing of
+back-to-back launches over rotating buffers, for A/B-ing kernel variants in one process."""
+import os, sys, json, argparse
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "gr-doa_amd", "python")]
+import torch
+import doa
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=4096)
+ap.add_argument("--reps", type=int, default=100)
+ap.add_argument("--nbuf", type=int, default=4)
+ap.add_argument("--precision", type=int, default=64)
+ap.add_argument("--stages", default="cov,music,peak,pipe")
+ap.add_argument("--streams", type=int, default=1)
+args = ap.parse_args()
+N, K, P, M, B = 4, 1024, 1024, 1, args.batch
+doa.set_internal_precision(args.precision)
+st = torch.cuda.current_stream()
+streams = []
+for b in range(args.nbuf):
+    x = torch.randn((N, B * K, 2), device="cuda", dtype=torch.float32)
+    streams.append([torch.view_as_complex(x[n].contiguous()) for n in range(N)])
+ptrs = [[t.data_ptr() for t in s] for s in streams]
+cov = [torch.empty((B, N * N), dtype=torch.complex64, device="cuda") for _ in range(args.nbuf)]
+spec = [torch.empty((B, P), dtype=torch.float32, device="cuda") for _ in range(args.nbuf)]
+mx = [torch.empty((B, M), dtype=torch.float32, device="cuda") for _ in range(args.nbuf)]
+am = [torch.empty((B, M), dtype=torch.float32, device="cuda") for _ in range(args.nbuf)]
+cov_blk = doa.autocorrelate(N, K, 0, 0)
+music_blk = doa.MUSIC_lin_array(0.5, M, N, P)
+peak_blk = doa.find_local_max(M, P, 0.0, 180.0)
+pipe = doa.music_pipeline(N, K, 0, 0, 0.5, M, P, B)
+
+def timeit(fn):
+    for i in range(10): fn(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = []
+    for r in range(5):
+        torch.cuda.synchronize(); e0.record(st)
+        for i in range(args.reps): fn(i)
+        e1.record(st); torch.cuda.synchronize()
+        best.append(e0.elapsed_time(e1) * 1e3 / args.reps)
+    return min(best), sorted(best)[len(best) // 2]
+
+nb = args.nbuf
+res = {}
+for i in range(nb):   # valid covariances in every buffer for the music stage
+    cov_blk.work_dev(B, ptrs[i], cov[i].data_ptr(), st)
+if "cov" in args.stages:
+    res["cov_us"] = timeit(lambda i: cov_blk.work_dev(B, ptrs[i % nb], cov[i % nb].data_ptr(), st))
+    res["cov_GBs"] = (N * K * 8 + N * N * 8) * B / res["cov_us"][0] / 1e3
+if "music" in args.stages:
+    res["music_us"] = timeit(lambda i: music_blk.work_dev(B, cov[i % nb].data_ptr(), spec[i % nb].data_ptr(), st))
+if "peak" in args.stages:
+    res["peak_us"] = timeit(lambda i: peak_blk.work_dev(B, spec[i % nb].data_ptr(), mx[i % nb].data_ptr(), am[i % nb].data_ptr(), st))
+if "pipe" in args.stages:
+    res["pipe_us"] = timeit(lambda i: pipe.work_dev(B, ptrs[i % nb], cov[i % nb].data_ptr(), spec[i % nb].data_ptr(),
+                                                    mx[i % nb].data_ptr(), am[i % nb].data_ptr(), st))
+    res["snapshots_per_s"] = B / res["pipe_us"][0] * 1e6
+if "mpipe" in args.stages:
+    # alternate steps over several streams, one pipeline handle (= workspace) per stream
+    S = args.streams
+    sts = [torch.cuda.Stream() for _ in range(S)]
+    pipes = [doa.music_pipeline(N, K, 0, 0, 0.5, M, P, B) for _ in range(S)]
+    def run(n):
+        for i in range(n):
+            k = i % S
+            pipes[k].work_dev(B, ptrs[i % nb], cov[i % nb].data_ptr(), spec[i % nb].data_ptr(), mx[i % nb].data_ptr(),
+                              am[i % nb].data_ptr(), sts[k])
+    import time
+    run(20); torch.cuda.synchronize()
+    ts = []
+    for r in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); run(args.reps); th = time.perf_counter(); torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / args.reps * 1e6)
+        res["mpipe_host_enqueue_us"] = (th - t0) / args.reps * 1e6
+    res["mpipe_streams"] = S
+    res["mpipe_us"] = (min(ts), sorted(ts)[2])
+    res["mpipe_snapshots_per_s"] = B / min(ts) * 1e6
+print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("DOA_")}, "batch": B, **res}))
