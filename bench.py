@@ -45,6 +45,20 @@ def algorithmic_bytes():
     return {"cov": cov, "evd": evd, "scan": scan, "peak": peak, "total": cov + evd + scan + peak}
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/*_pmc_hbm_traffic.csv: separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per
+    MI355X_MICROARCH.md §HBM) — PMC counters cannot be collected from inside this process."""
+    import csv
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.csv")))
+    if not files:
+        return None, None
+    for r in csv.DictReader(open(files[-1])):
+        if kernel_substr in r["kernel"]:
+            return float(r["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def cpu_baseline(budget_s=12.0):
     """Times the C restatement of the reference path (oracle/doa_oracle.c, kind "port") on this
     box's host cores over a bounded sample of the same workload.  When scipy's bundled OpenBLAS is
@@ -219,6 +233,7 @@ def main():
     total_snap = args.steps * BATCH * world
     value = total_snap / elapsed
     cov_gbs = ab["cov"] * BATCH / (t_cov * 1e-6) / 1e9
+    traffic, traffic_src = pmc_traffic("cov_wave_kernel<4")
     out = {
         "metric": "DoA snapshots/sec (autocorr+MUSIC+peak) @ N=4, 1024 samp, 1024 angles",
         "value": value,
@@ -240,7 +255,7 @@ def main():
         "pipeline_gbs": ab["total"] * value / world / 1e9,
         "roofline": {"bound": "hbm", "kernel": "cov_wave_kernel<4,true> (K1 covariance)",
                      "achieved": cov_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cov_gbs / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": ab["cov"] * BATCH, "avg_launch_us": t_cov},
+                     "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": ab["cov"] * BATCH, "avg_launch_us": t_cov},
         "kernels": {
             "K1_cov": {"us": t_cov, "GBs": cov_gbs},
             "K2-K4_music(evd+scan)": {"us": t_music, "GBs": (ab["evd"] + ab["scan"]) * BATCH / (t_music * 1e-6) / 1e9},

@@ -52,17 +52,33 @@ int internal_precision_bits();  // 32 or 64 (doa_set_internal_precision)
 // ---- device-side wave primitives (wave = 64 lanes on gfx950) -----------------------------------
 constexpr int kWave = 64;
 
+// Cross-lane moves without LDS: DPP row operations (gfx9 encodings) + one v_readlane.
+//   quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_ror:4 = 0x124, row_ror:8 = 0x128,
+//   row_bcast:15 = 0x142 (lane 15 of each row -> the next row), row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_move(float old, float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// Sum over the 64 lanes, returned wave-uniform (the total forms in row 3 and is read from lane 63).
 __device__ __forceinline__ float wave_allreduce_sum(float v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-    return v;
+    v += dpp_move<0xB1, 0xF>(0.f, v);
+    v += dpp_move<0x4E, 0xF>(0.f, v);
+    v += dpp_move<0x124, 0xF>(0.f, v);
+    v += dpp_move<0x128, 0xF>(0.f, v);       // every lane: sum of its row of 16
+    v += dpp_move<0x142, 0xA>(0.f, v);       // rows 1,3 += rows 0,2
+    v += dpp_move<0x143, 0xC>(0.f, v);       // rows 2,3 += row 1 (= rows 0+1)
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_allreduce_max(float v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, kWave));
-    return v;
+    v = fmaxf(v, dpp_move<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_move<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_move<0x124, 0xF>(v, v));
+    v = fmaxf(v, dpp_move<0x128, 0xF>(v, v));
+    v = fmaxf(v, dpp_move<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_move<0x143, 0xC>(v, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 }  // namespace doa

@@ -1,0 +1,162 @@
+// hip_blocks_impl.cc — the four hot-path GNU Radio block shells of gr-doa, implemented as thin
+// forwarders to the C ABI of libdoa_hip.so (include/doa_hip.h).  No arithmetic lives here: the shells
+// only keep the GNU Radio contracts the reference blocks have —
+//   autocorrelate           gr::block, history = overlap+1, forecast/consume_each of nonoverlap*n
+//                           (reference lib/autocorrelate_impl.cc:47-65,75-80,114)
+//   MUSIC_lin_array         gr::sync_block, vlen N^2 complex -> vlen P float (…/MUSIC_lin_array_impl.cc:47-50)
+//   find_local_max          gr::sync_block, two outputs of vlen M (…/find_local_max_impl.cc:47-50)
+//   rootMUSIC_linear_array  gr::sync_block, io_signature(1, M, M floats), port 0 written
+//                           (…/rootMUSIC_linear_array_impl.cc:46-49,96)
+// — and turn a failing ABI call into the behaviour a GNU Radio block has for it: constructors throw
+// std::runtime_error / std::invalid_argument (as antenna_correction_impl.cc:58-73 does), work()
+// returns WORK_DONE (-1) after logging, which stops the flowgraph.
+#include <doa/MUSIC_lin_array.h>
+#include <doa/autocorrelate.h>
+#include <doa/find_local_max.h>
+#include <doa/rootMUSIC_linear_array.h>
+
+#include <doa_hip.h>
+
+#include <iostream>
+#include <stdexcept>
+#include <string>
+
+namespace gr {
+namespace doa {
+namespace {
+
+[[noreturn]] void throw_create(const char *what)
+{
+    throw std::runtime_error(std::string(what) + ": " + doa_last_error());
+}
+
+int work_failed(const char *what, int status)
+{
+    std::cerr << what << ": libdoa_hip status " << status << " (" << doa_last_error() << ")" << std::endl;
+    return gr::block::WORK_DONE;
+}
+
+// ------------------------------------------------------------------------------------------------
+class autocorrelate_hip : public autocorrelate
+{
+    doa_autocorrelate_t *d_h;
+    int d_nonoverlap;
+
+public:
+    autocorrelate_hip(int inputs, int snapshot_size, int overlap_size, int avg_method)
+        : gr::block("autocorrelate", gr::io_signature::make(inputs, inputs, sizeof(gr_complex)),
+                    gr::io_signature::make(1, 1, sizeof(gr_complex) * inputs * inputs)),
+          d_h(doa_autocorrelate_create(inputs, snapshot_size, overlap_size, avg_method)),
+          d_nonoverlap(snapshot_size - overlap_size)
+    {
+        if (!d_h) throw_create("doa::autocorrelate");
+        set_history(doa_autocorrelate_history(d_h));          // overlap_size + 1
+    }
+    ~autocorrelate_hip() override { doa_autocorrelate_destroy(d_h); }
+
+    void forecast(int noutput_items, gr_vector_int &ninput_items_required) override
+    {
+        const int need = doa_autocorrelate_forecast(d_h, noutput_items);
+        for (auto &n : ninput_items_required) n = need;
+    }
+
+    int general_work(int noutput_items, gr_vector_int &, gr_vector_const_void_star &input_items,
+                     gr_vector_void_star &output_items) override
+    {
+        const int produced = doa_autocorrelate_work(d_h, noutput_items, input_items.data(), output_items[0]);
+        if (produced < 0) return work_failed("doa::autocorrelate", produced);
+        consume_each(d_nonoverlap * produced);
+        return produced;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+class MUSIC_lin_array_hip : public MUSIC_lin_array
+{
+    doa_MUSIC_lin_array_t *d_h;
+
+public:
+    MUSIC_lin_array_hip(float norm_spacing, int num_targets, int num_ant_ele, int pspectrum_len)
+        : gr::sync_block("MUSIC_lin_array", gr::io_signature::make(1, 1, sizeof(gr_complex) * num_ant_ele * num_ant_ele),
+                         gr::io_signature::make(1, 1, sizeof(float) * pspectrum_len)),
+          d_h(doa_MUSIC_lin_array_create(norm_spacing, num_targets, num_ant_ele, pspectrum_len))
+    {
+        if (!d_h) throw_create("doa::MUSIC_lin_array");
+    }
+    ~MUSIC_lin_array_hip() override
+    {
+        // the reference prints this counter from its destructor (lib/MUSIC_lin_array_impl.cc:92-95)
+        std::cout << "Total output items produced: " << doa_MUSIC_lin_array_items_total(d_h) << std::endl;
+        doa_MUSIC_lin_array_destroy(d_h);
+    }
+    int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) override
+    {
+        const int produced = doa_MUSIC_lin_array_work(d_h, noutput_items, input_items[0], output_items[0]);
+        return produced < 0 ? work_failed("doa::MUSIC_lin_array", produced) : produced;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+class find_local_max_hip : public find_local_max
+{
+    doa_find_local_max_t *d_h;
+
+public:
+    find_local_max_hip(int num_max_vals, int vector_len, float x_min, float x_max)
+        : gr::sync_block("find_local_max", gr::io_signature::make(1, 1, sizeof(float) * vector_len),
+                         gr::io_signature::make2(2, 2, num_max_vals * sizeof(float), num_max_vals * sizeof(float))),
+          d_h(doa_find_local_max_create(num_max_vals, vector_len, x_min, x_max))
+    {
+        if (!d_h) throw_create("doa::find_local_max");
+    }
+    ~find_local_max_hip() override { doa_find_local_max_destroy(d_h); }
+    int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) override
+    {
+        const int produced = doa_find_local_max_work(d_h, noutput_items, input_items[0], output_items[0], output_items[1]);
+        return produced < 0 ? work_failed("doa::find_local_max", produced) : produced;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+class rootMUSIC_linear_array_hip : public rootMUSIC_linear_array
+{
+    doa_rootMUSIC_linear_array_t *d_h;
+
+public:
+    rootMUSIC_linear_array_hip(float norm_spacing, int num_targets, int num_ant_ele)
+        : gr::sync_block("rootMUSIC_linear_array",
+                         gr::io_signature::make(1, 1, sizeof(gr_complex) * num_ant_ele * num_ant_ele),
+                         gr::io_signature::make(1, num_targets, num_targets * sizeof(float))),
+          d_h(doa_rootMUSIC_linear_array_create(norm_spacing, num_targets, num_ant_ele))
+    {
+        if (!d_h) throw_create("doa::rootMUSIC_linear_array");
+    }
+    ~rootMUSIC_linear_array_hip() override { doa_rootMUSIC_linear_array_destroy(d_h); }
+    int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) override
+    {
+        const int produced = doa_rootMUSIC_linear_array_work(d_h, noutput_items, input_items[0], output_items[0]);
+        return produced < 0 ? work_failed("doa::rootMUSIC_linear_array", produced) : produced;
+    }
+};
+
+}  // namespace
+
+autocorrelate::sptr autocorrelate::make(int inputs, int snapshot_size, int overlap_size, int avg_method)
+{
+    return gnuradio::get_initial_sptr(new autocorrelate_hip(inputs, snapshot_size, overlap_size, avg_method));
+}
+MUSIC_lin_array::sptr MUSIC_lin_array::make(float norm_spacing, int num_targets, int num_ant_ele, int pspectrum_len)
+{
+    return gnuradio::get_initial_sptr(new MUSIC_lin_array_hip(norm_spacing, num_targets, num_ant_ele, pspectrum_len));
+}
+find_local_max::sptr find_local_max::make(int num_max_vals, int vector_len, float x_min, float x_max)
+{
+    return gnuradio::get_initial_sptr(new find_local_max_hip(num_max_vals, vector_len, x_min, x_max));
+}
+rootMUSIC_linear_array::sptr rootMUSIC_linear_array::make(float norm_spacing, int num_targets, int num_ant_ele)
+{
+    return gnuradio::get_initial_sptr(new rootMUSIC_linear_array_hip(norm_spacing, num_targets, num_ant_ele));
+}
+
+}  // namespace doa
+}  // namespace gr

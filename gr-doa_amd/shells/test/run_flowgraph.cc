@@ -1,0 +1,80 @@
+// run_flowgraph — exercises the C++ block shells the way the reference's flowgraphs wire them
+// (apps/run_MUSIC_lin_array_simulation.grc, apps/run_RootMUSIC_lin_array_simulation.grc):
+//     N stream files -> autocorrelate -> MUSIC_lin_array -> find_local_max   (mode "music")
+//     N stream files -> autocorrelate -> rootMUSIC_linear_array               (mode "root")
+// Inputs/outputs are raw little-endian binary files so that the pytest driver (tests/
+// test_gpu_shells.py) can compare every port with the Python binding and the oracle.
+//
+// usage: run_flowgraph music|root <in_prefix> <out_prefix> inputs snapshot overlap avg norm_spacing
+//                      num_targets pspectrum_len max_noutput
+//   reads  <in_prefix>.ch<k>.c64   (gr_complex samples of stream k, no history)
+//   writes <out_prefix>.cov.c64, .spec.f32, .max.f32, .argmax.f32   (music)
+//          <out_prefix>.cov.c64, .aoa.f32                            (root)
+#include <doa/MUSIC_lin_array.h>
+#include <doa/autocorrelate.h>
+#include <doa/find_local_max.h>
+#include <doa/rootMUSIC_linear_array.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <string>
+
+using gr::lite::port_data;
+
+static port_data read_file(const std::string &path, size_t item_size)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    port_data d;
+    d.item_size = item_size;
+    d.bytes.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    return d;
+}
+static void write_file(const std::string &path, const port_data &d)
+{
+    std::ofstream f(path, std::ios::binary);
+    f.write(d.bytes.data(), (std::streamsize)d.bytes.size());
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 12) {
+        std::cerr << "usage: run_flowgraph music|root in_prefix out_prefix inputs snapshot overlap avg norm_spacing "
+                     "num_targets pspectrum_len max_noutput\n";
+        return 2;
+    }
+    const std::string mode = argv[1], in_prefix = argv[2], out_prefix = argv[3];
+    const int inputs = atoi(argv[4]), snapshot = atoi(argv[5]), overlap = atoi(argv[6]), avg = atoi(argv[7]);
+    const float d = (float)atof(argv[8]);
+    const int M = atoi(argv[9]), P = atoi(argv[10]), max_noutput = atoi(argv[11]);
+    try {
+        std::vector<port_data> streams;
+        for (int k = 0; k < inputs; k++) streams.push_back(read_file(in_prefix + ".ch" + std::to_string(k) + ".c64", sizeof(gr_complex)));
+
+        auto ac = gr::doa::autocorrelate::make(inputs, snapshot, overlap, avg);
+        auto cov = gr::lite::run_block(*ac, streams, 1, max_noutput);
+        write_file(out_prefix + ".cov.c64", cov[0]);
+
+        if (mode == "music") {
+            auto music = gr::doa::MUSIC_lin_array::make(d, M, inputs, P);
+            auto spec = gr::lite::run_block(*music, {cov[0]}, 1, max_noutput);
+            write_file(out_prefix + ".spec.f32", spec[0]);
+            auto fmax = gr::doa::find_local_max::make(M, P, 0.0f, 180.0f);
+            auto pk = gr::lite::run_block(*fmax, {spec[0]}, 2, max_noutput);
+            write_file(out_prefix + ".max.f32", pk[0]);
+            write_file(out_prefix + ".argmax.f32", pk[1]);
+            std::cout << "items: cov " << cov[0].items() << " spec " << spec[0].items() << " peaks " << pk[0].items() << std::endl;
+        } else {
+            auto root = gr::doa::rootMUSIC_linear_array::make(d, M, inputs);
+            auto aoa = gr::lite::run_block(*root, {cov[0]}, 1, max_noutput);
+            write_file(out_prefix + ".aoa.f32", aoa[0]);
+            std::cout << "items: cov " << cov[0].items() << " aoa " << aoa[0].items() << std::endl;
+        }
+    } catch (const std::exception &e) {
+        std::cerr << "run_flowgraph: " << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

@@ -13,8 +13,9 @@ ap.add_argument("--nbuf", type=int, default=4)
 ap.add_argument("--precision", type=int, default=64)
 ap.add_argument("--stages", default="cov,music,peak,pipe")
 ap.add_argument("--streams", type=int, default=1)
+ap.add_argument("--K", type=int, default=1024)
 args = ap.parse_args()
-N, K, P, M, B = 4, 1024, 1024, 1, args.batch
+N, K, P, M, B = 4, args.K, 1024, 1, args.batch
 doa.set_internal_precision(args.precision)
 st = torch.cuda.current_stream()
 streams = []
