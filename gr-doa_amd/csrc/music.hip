@@ -26,6 +26,7 @@
 #include "peak_device.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace doa {
@@ -364,11 +365,21 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
             else { zr[j][e] = 1; zi[j][e] = 0; }
         }
     }
-    for (int item = wave; item < n_items; item += n_waves) {
-        const T *co = coef + (size_t)item * (2 * N);   // wave-uniform address -> scalar loads
-        T c[2 * N];
+    // coefficient records arrive through scalar loads (wave-uniform address); the next item's record
+    // is requested before this item's arithmetic so its latency hides behind it
+    T c[2 * N], c_next[2 * N];
+    if (wave < n_items) {
 #pragma unroll
-        for (int k = 0; k < 2 * N; k++) c[k] = co[k];
+        for (int k = 0; k < 2 * N; k++) c_next[k] = coef[(size_t)wave * (2 * N) + k];
+    }
+    for (int item = wave; item < n_items; item += n_waves) {
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) c[k] = c_next[k];
+        const int nxt = item + n_waves;
+        if (nxt < n_items) {
+#pragma unroll
+            for (int k = 0; k < 2 * N; k++) c_next[k] = coef[(size_t)nxt * (2 * N) + k];
+        }
         float out[CH][4];
         float mx = -INFINITY;
 #pragma unroll
@@ -459,7 +470,8 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
     // enough waves to fill the chip several times over, few enough that each wave amortises its
     // z-table load over several items
     int blocks = (n_items + waves_per_block - 1) / waves_per_block;
-    const int max_blocks = 256 * 8;
+    static const int wpc = [] { const char *e = getenv("DOA_SCAN_WAVES_PER_CU"); return e ? atoi(e) : 8; }();
+    const int max_blocks = 256 * wpc / waves_per_block;   // default 8 waves per CU: 2 items per wave at batch 4096
     if (blocks > max_blocks) blocks = max_blocks;
     dim3 grid(blocks), block(waves_per_block * kWave);
     const int max_ch = (sizeof(T) == 4) ? 16 : 4;        // double z table: 4 chunks fit the register file

@@ -16,20 +16,34 @@ __device__ __forceinline__ bool cand_better(float v, int i, float bv, int bi)
     if (bi == INT_MAX) return true;
     return (v > bv) || (v == bv && i < bi);
 }
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ void argbest_step(float &v, int &i)
+{
+    // lanes of rows masked off receive their own (v, i) back, which never beats itself
+    const float ov = dpp_move<CTRL, ROW_MASK>(v, v);
+    const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xF, false);
+    if (cand_better(ov, oi, v, i)) { v = ov; i = oi; }
+}
+// wave-wide best (value, index) pair, returned wave-uniform; DPP only (no LDS traffic)
 __device__ __forceinline__ void wave_argbest(float &v, int &i)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float ov = __shfl_xor(v, m, kWave);
-        const int oi = __shfl_xor(i, m, kWave);
-        if (cand_better(ov, oi, v, i)) { v = ov; i = oi; }
-    }
+    argbest_step<0xB1, 0xF>(v, i);
+    argbest_step<0x4E, 0xF>(v, i);
+    argbest_step<0x124, 0xF>(v, i);
+    argbest_step<0x128, 0xF>(v, i);
+    argbest_step<0x142, 0xA>(v, i);
+    argbest_step<0x143, 0xC>(v, i);
+    v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    i = __builtin_amdgcn_readlane(i, 63);
 }
 __device__ __forceinline__ int wave_sum_int(int x)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, kWave);
-    return x;
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x124, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+    return __builtin_amdgcn_readlane(x, 63);
 }
 
 // v[j][e] = element 256*j + 4*lane + e of the vector (positions >= L hold anything).  Writes the
@@ -39,6 +53,28 @@ __device__ __forceinline__ void peak_pick(const float (&v)[CH][4], int lane, int
                                           const float *__restrict__ xaxis, float *__restrict__ out_val_item,
                                           float *__restrict__ out_loc_item)
 {
+    if (M == 1) {
+        // find_one_local_peak_indx = arma index_max (op_max::direct_max): best starts at -inf and is
+        // replaced only by a strictly greater element -> first occurrence of the maximum; NaNs never
+        // win; nothing above -inf -> index 0
+        float bv = 0.f;
+        int bi = INT_MAX;
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int p = 256 * j + 4 * lane + e;
+                if (p < L && v[j][e] > -INFINITY && cand_better(v[j][e], p, bv, bi)) { bv = v[j][e]; bi = p; }
+            }
+        wave_argbest(bv, bi);
+        const float v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[0][0]), 0));
+        if (lane == 0) {
+            const int idx = (bi == INT_MAX) ? 0 : bi;
+            out_val_item[0] = (bi == INT_MAX) ? v0 : bv;
+            out_loc_item[0] = xaxis[idx];
+        }
+        return;
+    }
     int sel_idx = INT_MAX;      // lane r keeps the r-th ranked index
     float sel_val = 0.f;
     int n_valid = 0, best_list_pos = 0;

@@ -8,6 +8,9 @@
 // unless the caller asks for them.
 #include "kernels.hpp"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace doa {
 bool find_local_max_fast_ok(int L, const void *d_in);
 int launch_find_local_max_serial(const PeakTables &t, int n_items, const void *d_in, void *d_max, void *d_argmax,
@@ -86,15 +89,25 @@ int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput_items, cons
     }
     if (noutput_items == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    // DOA_PIPE_SKIP=cov,evd,scan: profiling aid that drops stages (outputs are then meaningless)
+    static const unsigned skip = [] {
+        const char *e = getenv("DOA_PIPE_SKIP");
+        unsigned m = 0;
+        if (e) { if (strstr(e, "cov")) m |= 1; if (strstr(e, "evd")) m |= 2; if (strstr(e, "scan")) m |= 4; }
+        return m;
+    }();
     void *cov = d_cov_out ? d_cov_out : h->d_cov.p;
     void *spec = d_spectrum_out ? d_spectrum_out : h->d_spec.p;
-    int rc = doa::launch_autocorrelate(h->N, h->K, h->ovl, h->avg, noutput_items, d_input_items, cov, st);
+    int rc = DOA_OK;
+    if (!(skip & 1)) rc = doa::launch_autocorrelate(h->N, h->K, h->ovl, h->avg, noutput_items, d_input_items, cov, st);
     if (rc != DOA_OK) return rc;
     const bool dbl = (h->bits == 64);
-    rc = doa::launch_music_evd(h->N, h->music.M, noutput_items, cov, dbl ? nullptr : h->d_coef.p,
-                               dbl ? h->d_coef.p : nullptr, nullptr, h->bits, st);
+    if (!(skip & 2))
+        rc = doa::launch_music_evd(h->N, h->music.M, noutput_items, cov, dbl ? nullptr : h->d_coef.p,
+                                   dbl ? h->d_coef.p : nullptr, nullptr, h->bits, st);
     if (rc != DOA_OK) return rc;
     bool peaks_done = false;
+    if (skip & 4) return noutput_items;
     rc = doa::launch_music_scan(h->music, h->bits, noutput_items, h->d_coef.p, spec, nullptr, st, &h->peaks, d_max_out,
                                 d_argmax_out, &peaks_done);
     if (rc != DOA_OK) return rc;

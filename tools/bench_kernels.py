@@ -14,8 +14,12 @@ ap.add_argument("--precision", type=int, default=64)
 ap.add_argument("--stages", default="cov,music,peak,pipe")
 ap.add_argument("--streams", type=int, default=1)
 ap.add_argument("--K", type=int, default=1024)
+ap.add_argument("--N", type=int, default=4)
+ap.add_argument("--P", type=int, default=1024)
+ap.add_argument("--M", type=int, default=1)
+ap.add_argument("--ablate", default="", help="mcov: multi-stream covariance only; mmusic: multi-stream MUSIC only")
 args = ap.parse_args()
-N, K, P, M, B = 4, args.K, 1024, 1, args.batch
+N, K, P, M, B = args.N, args.K, args.P, args.M, args.batch
 doa.set_internal_precision(args.precision)
 st = torch.cuda.current_stream()
 streams = []
@@ -54,6 +58,10 @@ if "music" in args.stages:
     res["music_us"] = timeit(lambda i: music_blk.work_dev(B, cov[i % nb].data_ptr(), spec[i % nb].data_ptr(), st))
 if "peak" in args.stages:
     res["peak_us"] = timeit(lambda i: peak_blk.work_dev(B, spec[i % nb].data_ptr(), mx[i % nb].data_ptr(), am[i % nb].data_ptr(), st))
+if "root" in args.stages:
+    root_blk = doa.rootMUSIC_linear_array(0.5, M, N)
+    ang = [torch.empty((B, M), dtype=torch.float32, device="cuda") for _ in range(nb)]
+    res["root_us"] = timeit(lambda i: root_blk.work_dev(B, cov[i % nb].data_ptr(), ang[i % nb].data_ptr(), st))
 if "pipe" in args.stages:
     res["pipe_us"] = timeit(lambda i: pipe.work_dev(B, ptrs[i % nb], cov[i % nb].data_ptr(), spec[i % nb].data_ptr(),
                                                     mx[i % nb].data_ptr(), am[i % nb].data_ptr(), st))
@@ -78,4 +86,24 @@ if "mpipe" in args.stages:
     res["mpipe_streams"] = S
     res["mpipe_us"] = (min(ts), sorted(ts)[2])
     res["mpipe_snapshots_per_s"] = B / min(ts) * 1e6
+if args.ablate:
+    import time
+    S = args.streams
+    sts = [torch.cuda.Stream() for _ in range(S)]
+    covs = [doa.autocorrelate(N, K, 0, 0) for _ in range(S)]
+    mus = [doa.music_pipeline(N, K, 0, 0, 0.5, M, P, B) for _ in range(S)]
+    mbl = [doa.MUSIC_lin_array(0.5, M, N, P) for _ in range(S)]
+    def run(n):
+        for i in range(n):
+            k = i % S
+            if "mcov" in args.ablate:
+                covs[k].work_dev(B, ptrs[i % nb], cov[i % nb].data_ptr(), sts[k])
+            if "mmusic" in args.ablate:
+                mbl[k].work_dev(B, cov[i % nb].data_ptr(), spec[i % nb].data_ptr(), sts[k])
+    run(20); torch.cuda.synchronize()
+    ts = []
+    for r in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); run(args.reps); torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / args.reps * 1e6)
+    res["ablate"] = args.ablate; res["ablate_streams"] = S; res["ablate_us"] = (min(ts), sorted(ts)[2])
 print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("DOA_")}, "batch": B, **res}))
