@@ -236,6 +236,74 @@ template <bool VEC2> __global__ __launch_bounds__(256) void cov_tile_kernel(CovA
     }
 }
 
+// Wide arrays (8 < N <= 16): the per-snapshot outer-product sum is a 16 x K by K x 16 complex GEMM,
+// run on the matrix cores as four real v_mfma_f32_16x16x4_f32 per 4-sample step (exact fp32, same
+// rate as the vector FMA pipe but with the whole 16 x 16 accumulator held in 8 registers):
+//     Re R += Xr Xr^T + Xi Xi^T,      Im R += Xi Xr^T - Xr Xi^T.
+// One wave owns one snapshot.  Lane l = (channel l&15, sample group l>>4) loads 4 consecutive samples
+// (two 16-byte loads; 128 B contiguous per channel per wave-iteration) and feeds the SAME register as
+// the A and the B operand (A[a][k] = x_a[t_k], B[k][b] = x_b[t_k]); channels >= N contribute zeros.
+// No cross-lane reduction is needed: the K dimension is summed inside the MFMA accumulators, whose
+// C/D layout (row = 4*(l>>4)+reg, col = l&15) is written straight to the column-major item.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <bool VEC2> __global__ __launch_bounds__(256) void cov_mfma_kernel(CovArgs g)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave0 = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const int n_waves = gridDim.x * (blockDim.x / kWave);
+    const int ch = lane & 15, grp = lane >> 4;
+    const bool live = ch < g.n_ch;
+    const float2 *src = g.in[live ? ch : 0];
+    for (int snap = wave0; snap < g.n_out; snap += n_waves) {
+        const float2 *p = src + (size_t)snap * (size_t)g.S + 4 * grp;
+        f32x4_t acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = {0.f, 0.f, 0.f, 0.f};
+        auto step = [&](float xr, float xi) {
+            acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, xr, acc_re, 0, 0, 0);
+            acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(xi, xr, acc_im, 0, 0, 0);
+            acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(xi, xi, acc_re, 0, 0, 0);
+            acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(-xr, xi, acc_im, 0, 0, 0);
+        };
+        int t = 0;
+        constexpr int UN = 4;                          // 4 wave-iterations (64 samples) of loads in flight
+        for (; t + 16 * UN <= g.K; t += 16 * UN) {
+            float2 x[UN][4];
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                if constexpr (VEC2) {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(p + t + 16 * u);
+                    const float4 v1 = *reinterpret_cast<const float4 *>(p + t + 16 * u + 2);
+                    x[u][0] = make_float2(v0.x, v0.y); x[u][1] = make_float2(v0.z, v0.w);
+                    x[u][2] = make_float2(v1.x, v1.y); x[u][3] = make_float2(v1.z, v1.w);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) x[u][j] = p[t + 16 * u + j];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; u++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) step(live ? x[u][j].x : 0.f, live ? x[u][j].y : 0.f);
+        }
+        for (; t < g.K; t += 16) {                      // remainder, sample by sample with bounds checks
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int sidx = t + 4 * grp + j;
+                float2 v = make_float2(0.f, 0.f);
+                if (live && sidx < g.K) v = p[t + j];
+                step(v.x, v.y);
+            }
+        }
+        float2 *item = g.out + (size_t)snap * g.n_ch * g.n_ch;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int a = 4 * grp + r;
+            if (a < g.n_ch && live)
+                item[a + (size_t)ch * g.n_ch] = make_float2(__fmul_rn(acc_re[r], g.inv_k), __fmul_rn(acc_im[r], g.inv_k));
+        }
+    }
+}
+
 // R <- 0.5 R + (0.5/K) conj(R[N-1-a, N-1-b]), pairwise in place (element e with N^2-1-e).
 __global__ void cov_fb_kernel(float2 *out, int nn, long long n_items, float fb_hk)
 {
@@ -326,13 +394,21 @@ int launch_autocorrelate(int N, int K, int ovl, int avg, int n_out, const void *
     case 7: launch_wave<7>(g, vec2, st); break;
     case 8: launch_wave<8>(g, vec2, st); break;
     default: {
-        dim3 grid((n_out + 3) / 4), block(256);
-        for (int a0 = 0; a0 < N; a0 += 8)
-            for (int b0 = a0; b0 < N; b0 += 8) {
-                g.a0 = a0; g.b0 = b0;
-                if (vec2) hipLaunchKernelGGL(cov_tile_kernel<true>, grid, block, 0, st, g);
-                else      hipLaunchKernelGGL(cov_tile_kernel<false>, grid, block, 0, st, g);
-            }
+        static const int use_tiles = [] { const char *e = getenv("DOA_COV_TILES"); return e ? atoi(e) : 0; }();
+        if (use_tiles) {                 // VALU 8x8 register tiles (kept for A/B against the MFMA kernel)
+            dim3 grid((n_out + 3) / 4), block(256);
+            for (int a0 = 0; a0 < N; a0 += 8)
+                for (int b0 = a0; b0 < N; b0 += 8) {
+                    g.a0 = a0; g.b0 = b0;
+                    if (vec2) hipLaunchKernelGGL(cov_tile_kernel<true>, grid, block, 0, st, g);
+                    else      hipLaunchKernelGGL(cov_tile_kernel<false>, grid, block, 0, st, g);
+                }
+        } else {
+            int blocks = (n_out + 3) / 4;
+            if (blocks > 256 * 4) blocks = 256 * 4;        // <= 16 waves per CU, grid-stride beyond
+            if (vec2) hipLaunchKernelGGL(cov_mfma_kernel<true>, dim3(blocks), dim3(256), 0, st, g);
+            else      hipLaunchKernelGGL(cov_mfma_kernel<false>, dim3(blocks), dim3(256), 0, st, g);
+        }
         if (avg == 1) {
             const int nn = N * N, half = (nn + 1) / 2;
             const long long total = (long long)n_out * half;
