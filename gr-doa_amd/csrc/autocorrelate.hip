@@ -29,6 +29,7 @@ struct CovArgs {
     float inv_k;   // (float)(1.0/K)
     float fb_hk;   // (float)(0.5/K)
     int a0, b0;    // tile origin (tile kernel only)
+    const float2 *gain;   // optional [N*N] g_a conj(g_b) (fused antenna_correction), or nullptr
 };
 
 template <int TN> struct TriAcc {
@@ -146,6 +147,10 @@ __global__ __launch_bounds__(256) void cov_wave_kernel(CovArgs g)
     }
     r.x = __fmul_rn(r.x, g.inv_k);
     r.y = __fmul_rn(r.y, g.inv_k);
+    if (g.gain && lane < TN * TN) {            // fused antenna correction: R[a,b] *= g_a conj(g_b)
+        const float2 w = g.gain[lane];
+        r = make_float2(fmaf(w.x, r.x, -w.y * r.y), fmaf(w.x, r.y, w.y * r.x));
+    }
     if (g.avg == 1) {
         // (J conj(R) J)[a,b] = conj(R[N-1-a, N-1-b])  ->  element index N^2-1-e
         const int src = (lane < TN * TN) ? (TN * TN - 1 - lane) : lane;
@@ -230,6 +235,10 @@ template <bool VEC2> __global__ __launch_bounds__(256) void cov_tile_kernel(CovA
     r.y = __fmul_rn(r.y, g.inv_k);
     const int a = g.a0 + (lane & (T - 1)), b = g.b0 + (lane >> 3);
     if (a < g.n_ch && b < g.n_ch) {
+        if (g.gain) {
+            const float2 w = g.gain[a + b * g.n_ch];
+            r = make_float2(fmaf(w.x, r.x, -w.y * r.y), fmaf(w.x, r.y, w.y * r.x));
+        }
         float2 *item = g.out + (size_t)snap * g.n_ch * g.n_ch;
         item[a + (size_t)b * g.n_ch] = r;
         if (g.a0 != g.b0) item[b + (size_t)a * g.n_ch] = make_float2(r.x, -r.y);
@@ -298,8 +307,14 @@ template <bool VEC2> __global__ __launch_bounds__(256) void cov_mfma_kernel(CovA
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int a = 4 * grp + r;
-            if (a < g.n_ch && live)
-                item[a + (size_t)ch * g.n_ch] = make_float2(__fmul_rn(acc_re[r], g.inv_k), __fmul_rn(acc_im[r], g.inv_k));
+            if (a < g.n_ch && live) {
+                float2 v = make_float2(__fmul_rn(acc_re[r], g.inv_k), __fmul_rn(acc_im[r], g.inv_k));
+                if (g.gain) {
+                    const float2 w = g.gain[a + ch * g.n_ch];
+                    v = make_float2(fmaf(w.x, v.x, -w.y * v.y), fmaf(w.x, v.y, w.y * v.x));
+                }
+                item[a + (size_t)ch * g.n_ch] = v;
+            }
         }
     }
 }
@@ -367,7 +382,7 @@ template <int TN> static void launch_wave(const CovArgs &g, bool vec2, hipStream
 
 // Launches K1 on `st`.  d_in: N device pointers.  Returns DOA_OK / error.
 int launch_autocorrelate(int N, int K, int ovl, int avg, int n_out, const void *const *d_in, void *d_out,
-                         hipStream_t st)
+                         hipStream_t st, const void *d_gain_outer)
 {
     if (n_out <= 0) return DOA_OK;
     CovArgs g;
@@ -384,6 +399,7 @@ int launch_autocorrelate(int N, int K, int ovl, int avg, int n_out, const void *
     g.n_ch = N; g.K = K; g.S = K - ovl; g.n_out = n_out; g.avg = avg;
     g.inv_k = (float)(1.0 / K);
     g.fb_hk = (float)(0.5 / K);
+    g.gain = static_cast<const float2 *>(d_gain_outer);
     switch (N) {
     case 1: launch_wave<1>(g, vec2, st); break;
     case 2: launch_wave<2>(g, vec2, st); break;
@@ -430,7 +446,8 @@ struct doa_autocorrelate {
     int inputs, snapshot, overlap, avg;
     int device;
     hipStream_t stream = nullptr;
-    doa::DevBuf d_in, d_out;
+    doa::DevBuf d_in, d_out, d_gain;
+    bool has_gain = false;
 };
 
 extern "C" {
@@ -468,8 +485,28 @@ void doa_autocorrelate_destroy(doa_autocorrelate_t *h)
     if (!h) return;
     h->d_in.release();
     h->d_out.release();
+    h->d_gain.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+}
+
+int doa_autocorrelate_fuse_antenna_correction(doa_autocorrelate_t *h, const float *gains_re_im)
+{
+    doa::clear_error();
+    if (!h) return DOA_ERR_INVALID_ARG;
+    if (!gains_re_im) { h->has_gain = false; return DOA_OK; }
+    const int N = h->inputs;
+    float2 w[DOA_MAX_ANT_ELE * DOA_MAX_ANT_ELE];
+    for (int b = 0; b < N; b++)
+        for (int a = 0; a < N; a++) {
+            const float ar = gains_re_im[2 * a], ai = gains_re_im[2 * a + 1], br = gains_re_im[2 * b], bi = gains_re_im[2 * b + 1];
+            w[a + b * N] = make_float2(ar * br + ai * bi, ai * br - ar * bi);   // g_a conj(g_b)
+        }
+    int rc = h->d_gain.reserve(sizeof(float2) * N * N);
+    if (rc != DOA_OK) return rc;
+    DOA_HIP_TRY(hipMemcpy(h->d_gain.p, w, sizeof(float2) * N * N, hipMemcpyHostToDevice));
+    h->has_gain = true;
+    return DOA_OK;
 }
 
 int doa_autocorrelate_history(const doa_autocorrelate_t *h) { return h ? h->overlap + 1 : DOA_ERR_INVALID_ARG; }
@@ -495,7 +532,8 @@ int doa_autocorrelate_work_dev(doa_autocorrelate_t *h, int noutput_items, const 
         return DOA_ERR_INVALID_ARG;
     }
     int rc = doa::launch_autocorrelate(h->inputs, h->snapshot, h->overlap, h->avg, noutput_items, d_input_items,
-                                       d_output_items0, static_cast<hipStream_t>(hip_stream));
+                                       d_output_items0, static_cast<hipStream_t>(hip_stream),
+                                       h->has_gain ? h->d_gain.p : nullptr);
     return rc == DOA_OK ? noutput_items : rc;
 }
 
@@ -523,7 +561,8 @@ int doa_autocorrelate_work(doa_autocorrelate_t *h, int noutput_items, const void
         DOA_HIP_TRY(hipMemcpyAsync(dst, input_items[k], span * sizeof(float2), hipMemcpyHostToDevice, h->stream));
         d_ptrs[k] = dst;
     }
-    rc = doa::launch_autocorrelate(N, h->snapshot, h->overlap, h->avg, noutput_items, d_ptrs, h->d_out.p, h->stream);
+    rc = doa::launch_autocorrelate(N, h->snapshot, h->overlap, h->avg, noutput_items, d_ptrs, h->d_out.p, h->stream,
+                                   h->has_gain ? h->d_gain.p : nullptr);
     if (rc != DOA_OK) return rc;
     DOA_HIP_TRY(hipMemcpyAsync(output_items0, h->d_out.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
     DOA_HIP_TRY(hipStreamSynchronize(h->stream));

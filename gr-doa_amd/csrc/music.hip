@@ -282,6 +282,163 @@ __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict_
     if (cd) cd[2 * N - 1] = 0.0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// N > 4: the same Jacobi with the matrices in LDS instead of registers.  One lane per item still
+// (no barriers: a lane only ever touches its own column of the [element][lane] LDS image, which is
+// also bank-conflict free), but A's packed upper triangle, V and the result scratch live in LDS
+// where run-time row/column indices cost nothing; 3N^2+3N values per item bound the lanes per
+// block (double: 64 lanes at N = 8, 25 at N = 16, one block per CU).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void music_evd_lds_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
+                                                           double *__restrict__ coef_d, float2 *__restrict__ pn_out,
+                                                           int n_items, int N, int M, int LB)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *sm = reinterpret_cast<T *>(smem_raw);
+    const int lane = threadIdx.x;
+    const int item = blockIdx.x * LB + lane;
+    if (lane >= LB || item >= n_items) return;
+    const int NT = N * (N - 1) / 2;
+    // LDS image, element-major: dg[N] | ur[NT] | ui[NT] | vr[N*N] | vi[N*N] | cu_r[N] | cu_i[N]
+    auto at = [&](int e) -> T & { return sm[(size_t)e * LB + lane]; };
+    const int oDG = 0, oUR = N, oUI = N + NT, oVR = N + 2 * NT, oVI = oVR + N * N, oCR = oVI + N * N, oCI = oCR + N;
+    auto tri = [&](int r, int c) { return r * N - r * (r + 1) / 2 + (c - r - 1); };   // r < c
+
+    const float2 *Ri = R + (size_t)item * (N * N);
+    for (int c = 0; c < N; c++)
+        for (int r = 0; r <= c; r++) {
+            const float2 x = Ri[r + c * N];
+            if (r == c) at(oDG + r) = (T)x.x;
+            else { at(oUR + tri(r, c)) = (T)x.x; at(oUI + tri(r, c)) = (T)x.y; }
+        }
+    for (int r = 0; r < N; r++)
+        for (int c = 0; c < N; c++) { at(oVR + r * N + c) = (r == c) ? (T)1 : (T)0; at(oVI + r * N + c) = 0; }
+
+    const int max_sweeps = Real<T>::max_sweeps + 2 * N;
+    for (int sweep = 0; sweep < max_sweeps; sweep++) {
+        T off = 0, dn = 0;
+        for (int p = 0; p < N; p++) dn = fma(at(oDG + p), at(oDG + p), dn);
+        for (int e = 0; e < NT; e++) off += at(oUR + e) * at(oUR + e) + at(oUI + e) * at(oUI + e);
+        if (!(off > Real<T>::tol * dn) || !(off > Real<T>::tiny)) break;
+        for (int p = 0; p < N - 1; p++) {
+            for (int q = p + 1; q < N; q++) {
+                const int epq = tri(p, q);
+                const T apr = at(oUR + epq), api = at(oUI + epq);
+                const T g2 = apr * apr + api * api;
+                if (!(g2 > Real<T>::tiny)) continue;
+                const T inv_g = Real<T>::rsqrt(g2);
+                const T g = g2 * inv_g;
+                const T phr = apr * inv_g, phi = api * inv_g;
+                const T app = at(oDG + p), aqq = at(oDG + q);
+                T tau = (aqq - app) * (T)0.5 * inv_g;
+                tau = fmin(fmax(tau, -Real<T>::tau_max), Real<T>::tau_max);
+                const T x1 = fma(tau, tau, (T)1);
+                const T r = x1 * Real<T>::rsqrt(x1);
+                const T h = fabs(tau) + r;
+                const T w = Real<T>::rsqrt(fma(h, h, (T)1));
+                const T c = h * w;
+                const T s = copysign(w, tau);
+                const T spr = s * phr, spi = s * phi;
+                const T cc = c * c, ss = s * s, csg = (T)2 * c * s * g;
+                at(oDG + p) = fma(cc, app, fma(ss, aqq, -csg));
+                at(oDG + q) = fma(ss, app, fma(cc, aqq, csg));
+                at(oUR + epq) = 0; at(oUI + epq) = 0;
+                for (int k = 0; k < N; k++) {
+                    if (k == p || k == q) continue;
+                    const int ekp = (k < p) ? tri(k, p) : tri(p, k);
+                    const int ekq = (k < q) ? tri(k, q) : tri(q, k);
+                    const T sgp = (k < p) ? (T)1 : (T)-1, sgq = (k < q) ? (T)1 : (T)-1;   // conj when stored transposed
+                    const T xr = at(oUR + ekp), xi = sgp * at(oUI + ekp);
+                    const T yr = at(oUR + ekq), yi = sgq * at(oUI + ekq);
+                    const T nxr = c * xr - (spr * yr + spi * yi);
+                    const T nxi = c * xi - (spr * yi - spi * yr);
+                    const T nyr = c * yr + (spr * xr - spi * xi);
+                    const T nyi = c * yi + (spr * xi + spi * xr);
+                    at(oUR + ekp) = nxr; at(oUI + ekp) = sgp * nxi;
+                    at(oUR + ekq) = nyr; at(oUI + ekq) = sgq * nyi;
+                }
+                for (int k = 0; k < N; k++) {
+                    const T kpr = at(oVR + k * N + p), kpi = at(oVI + k * N + p);
+                    const T kqr = at(oVR + k * N + q), kqi = at(oVI + k * N + q);
+                    at(oVR + k * N + p) = c * kpr - (spr * kqr + spi * kqi);
+                    at(oVI + k * N + p) = c * kpi - (spr * kqi - spi * kqr);
+                    at(oVR + k * N + q) = c * kqr + (spr * kpr - spi * kpi);
+                    at(oVI + k * N + q) = c * kqi + (spr * kpi + spi * kpr);
+                }
+            }
+        }
+    }
+    // noise set: ascending rank < N-M (bit i of sel)
+    unsigned sel = 0;
+    for (int i = 0; i < N; i++) {
+        int rank = 0;
+        const T wi = at(oDG + i);
+        for (int j = 0; j < N; j++) {
+            const T wj = at(oDG + j);
+            rank += ((wj < wi) || (wj == wi && j < i)) ? 1 : 0;
+        }
+        if (rank < N - M) sel |= 1u << i;
+    }
+    for (int l = 0; l < N; l++) { at(oCR + l) = 0; at(oCI + l) = 0; }
+    float2 *po = pn_out ? pn_out + (size_t)item * (N * N) : nullptr;
+    for (int a = 0; a < N; a++)
+        for (int b = a; b < N; b++) {
+            T pr = 0, pi = 0;
+            for (int i = 0; i < N; i++)
+                if ((sel >> i) & 1u) {
+                    const T ar_ = at(oVR + a * N + i), ai_ = at(oVI + a * N + i);
+                    const T br_ = at(oVR + b * N + i), bi_ = at(oVI + b * N + i);
+                    pr = fma(ar_, br_, fma(ai_, bi_, pr));
+                    pi = fma(ai_, br_, fma(-ar_, bi_, pi));
+                }
+            // u_l = sum_r P[r+l][r] = conj(sum_r P[r][r+l])
+            at(oCR + (b - a)) += pr;
+            at(oCI + (b - a)) -= pi;
+            if (po) {
+                po[a + b * N] = make_float2((float)pr, (float)pi);
+                if (a != b) po[b + a * N] = make_float2((float)pr, -(float)pi);
+            }
+        }
+    float *co = coef ? coef + (size_t)item * (2 * N) : nullptr;
+    double *cd = coef_d ? coef_d + (size_t)item * (2 * N) : nullptr;
+    for (int l = 0; l < N; l++) {
+        const T ur_ = at(oCR + l), ui_ = at(oCI + l);
+        if (l == 0) {
+            if (co) co[0] = (float)ur_;
+            if (cd) cd[0] = (double)ur_;
+        } else {
+            if (co) { co[2 * l - 1] = (float)ur_; co[2 * l] = (float)ui_; }
+            if (cd) { cd[2 * l - 1] = (double)ur_; cd[2 * l] = (double)ui_; }
+        }
+    }
+    if (co) co[2 * N - 1] = 0.f;
+    if (cd) cd[2 * N - 1] = 0.0;
+}
+
+template <typename T>
+static int launch_evd_lds(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
+                          hipStream_t st)
+{
+    const size_t per_item = (size_t)(3 * N * N + 3 * N) * sizeof(T);   // generous bound on the LDS image
+    const size_t budget = 156 * 1024;
+    int LB = (int)(budget / per_item);
+    if (LB > 64) LB = 64;
+    if (LB < 1) { set_error("MUSIC: LDS image of one %dx%d item does not fit", N, N); return DOA_ERR_UNSUPPORTED; }
+    const size_t bytes = per_item * LB;
+    static size_t configured_f = 0, configured_d = 0;
+    size_t &configured = (sizeof(T) == 4) ? configured_f : configured_d;
+    if (bytes > configured) {
+        DOA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&music_evd_lds_kernel<T>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        configured = 160 * 1024;
+    }
+    dim3 block(64), grid((n_items + LB - 1) / LB);
+    hipLaunchKernelGGL((music_evd_lds_kernel<T>), grid, block, bytes, st, (const float2 *)d_R, (float *)d_coef,
+                       (double *)d_coef_d, (float2 *)d_pn, n_items, N, M, LB);
+    return DOA_OK;
+}
+
 template <int N> static void launch_evd_n(int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
                                           int bits, hipStream_t st)
 {
@@ -298,15 +455,19 @@ int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, v
                      int evd_bits, hipStream_t st)
 {
     if (n_items <= 0) return DOA_OK;
-    switch (N) {
-#define DOA_EVD_CASE(n) case n: launch_evd_n<n>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
-        DOA_EVD_CASE(2) DOA_EVD_CASE(3) DOA_EVD_CASE(4) DOA_EVD_CASE(5) DOA_EVD_CASE(6) DOA_EVD_CASE(7)
-        DOA_EVD_CASE(8) DOA_EVD_CASE(9) DOA_EVD_CASE(10) DOA_EVD_CASE(11) DOA_EVD_CASE(12) DOA_EVD_CASE(13)
-        DOA_EVD_CASE(14) DOA_EVD_CASE(15) DOA_EVD_CASE(16)
-#undef DOA_EVD_CASE
-    default:
+    if (N < 2 || N > DOA_MAX_ANT_ELE) {
         set_error("MUSIC: num_ant_ele=%d outside the built range 2..%d", N, DOA_MAX_ANT_ELE);
         return DOA_ERR_UNSUPPORTED;
+    }
+    switch (N) {
+    case 2: launch_evd_n<2>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
+    case 3: launch_evd_n<3>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
+    case 4: launch_evd_n<4>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
+    default: {
+        const int rc = (evd_bits == 32) ? launch_evd_lds<float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st)
+                                        : launch_evd_lds<double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
+        if (rc != DOA_OK) return rc;
+    }
     }
     DOA_HIP_TRY(hipGetLastError());
     return DOA_OK;

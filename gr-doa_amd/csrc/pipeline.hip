@@ -24,7 +24,8 @@ struct doa_music_pipeline {
     int device = 0;
     doa::MusicTables music;
     doa::PeakTables peaks;
-    doa::DevBuf d_cov, d_coef, d_spec, d_scratch;
+    doa::DevBuf d_cov, d_coef, d_spec, d_scratch, d_gain;
+    bool has_gain = false;
 };
 
 extern "C" {
@@ -70,8 +71,27 @@ void doa_music_pipeline_destroy(doa_music_pipeline_t *h)
     if (!h) return;
     h->music.release();
     h->peaks.release();
-    h->d_cov.release(); h->d_coef.release(); h->d_spec.release(); h->d_scratch.release();
+    h->d_cov.release(); h->d_coef.release(); h->d_spec.release(); h->d_scratch.release(); h->d_gain.release();
     delete h;
+}
+
+int doa_music_pipeline_fuse_antenna_correction(doa_music_pipeline_t *h, const float *gains_re_im)
+{
+    doa::clear_error();
+    if (!h) return DOA_ERR_INVALID_ARG;
+    if (!gains_re_im) { h->has_gain = false; return DOA_OK; }
+    const int N = h->N;
+    float2 w[DOA_MAX_ANT_ELE * DOA_MAX_ANT_ELE];
+    for (int b = 0; b < N; b++)
+        for (int a = 0; a < N; a++) {
+            const float ar = gains_re_im[2 * a], ai = gains_re_im[2 * a + 1], br = gains_re_im[2 * b], bi = gains_re_im[2 * b + 1];
+            w[a + b * N] = make_float2(ar * br + ai * bi, ai * br - ar * bi);   // g_a conj(g_b)
+        }
+    int rc = h->d_gain.reserve(sizeof(float2) * N * N);
+    if (rc != DOA_OK) return rc;
+    DOA_HIP_TRY(hipMemcpy(h->d_gain.p, w, sizeof(float2) * N * N, hipMemcpyHostToDevice));
+    h->has_gain = true;
+    return DOA_OK;
 }
 
 int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput_items, const void *const *d_input_items,
@@ -99,7 +119,8 @@ int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput_items, cons
     void *cov = d_cov_out ? d_cov_out : h->d_cov.p;
     void *spec = d_spectrum_out ? d_spectrum_out : h->d_spec.p;
     int rc = DOA_OK;
-    if (!(skip & 1)) rc = doa::launch_autocorrelate(h->N, h->K, h->ovl, h->avg, noutput_items, d_input_items, cov, st);
+    if (!(skip & 1)) rc = doa::launch_autocorrelate(h->N, h->K, h->ovl, h->avg, noutput_items, d_input_items, cov, st,
+                                                     h->has_gain ? h->d_gain.p : nullptr);
     if (rc != DOA_OK) return rc;
     const bool dbl = (h->bits == 64);
     if (!(skip & 2))

@@ -83,6 +83,13 @@ SIGNATURES = {
     "doa_rootMUSIC_linear_array_destroy": (None, [_vp]),
     "doa_rootMUSIC_linear_array_work": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "doa_rootMUSIC_linear_array_work_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "doa_antenna_correction_create": (_vp, [C.c_int, C.c_char_p]),
+    "doa_antenna_correction_destroy": (None, [_vp]),
+    "doa_antenna_correction_gains": (C.c_int, [_vp, _vp]),
+    "doa_antenna_correction_work": (C.c_int, [_vp, C.c_int, _vpp, _vpp]),
+    "doa_antenna_correction_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vpp, _vp]),
+    "doa_autocorrelate_fuse_antenna_correction": (C.c_int, [_vp, _vp]),
+    "doa_music_pipeline_fuse_antenna_correction": (C.c_int, [_vp, _vp]),
     "doa_music_pipeline_create": (_vp, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]),
     "doa_music_pipeline_destroy": (None, [_vp]),
     "doa_music_pipeline_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp, _vp]),

@@ -106,6 +106,58 @@ class autocorrelate(_Block):
         return check(lib.doa_autocorrelate_work_dev(self._h, int(noutput_items), ptr_array(d_input_ptrs),
                                                     C.c_void_p(int(d_out_ptr)), _stream_ptr(stream)))
 
+    def fuse_antenna_correction(self, correction) -> None:
+        """Fold a doa.antenna_correction block (or an array of complex gains, or None to undo) into
+        this block: equivalent to wiring the correction block in front of it."""
+        _fuse(lib.doa_autocorrelate_fuse_antenna_correction, self._h, correction, self.inputs)
+
+
+def _fuse(fn, handle, correction, n):
+    if correction is None:
+        check(fn(handle, C.c_void_p(0)))
+        return
+    g = correction.gains() if hasattr(correction, "gains") else np.asarray(correction)
+    g = np.ascontiguousarray(np.asarray(g, dtype=_C64).reshape(n))
+    check(fn(handle, _vp(g)))
+
+
+class antenna_correction(_Block):
+    """doa.antenna_correction(num_inputs, config_filename) — gr::sync_block, N complex streams in
+    and out (reference lib/antenna_correction_impl.cc:47-99).  Raises ValueError with the
+    reference's std::invalid_argument text for a missing / too long / too short config file."""
+
+    _destroy = staticmethod(lib.doa_antenna_correction_destroy)
+
+    def __init__(self, num_inputs, config_filename):
+        super().__init__()
+        self.num_ant_ele = int(num_inputs)
+        h = lib.doa_antenna_correction_create(self.num_ant_ele, str(config_filename).encode())
+        if not h:
+            msg = _lib.last_error()
+            if msg.startswith(("Cannot find configuration", "Configuration file")):
+                raise ValueError(msg)                   # std::invalid_argument in the reference
+            raise _lib.DoaError(-1, msg or "antenna_correction: create failed")
+        self._h = h
+        self.in_sig = [(_C64, 1)] * self.num_ant_ele
+        self.out_sig = [(_C64, 1)] * self.num_ant_ele
+
+    def gains(self) -> np.ndarray:
+        g = np.empty(self.num_ant_ele, dtype=_C64)
+        check(lib.doa_antenna_correction_gains(self._h, _vp(g)))
+        return g
+
+    def work(self, noutput_items, input_items, output_items) -> int:
+        n = int(noutput_items)
+        ins = [np.ascontiguousarray(a, dtype=_C64) for a in input_items]
+        for a, o in zip(ins, output_items):
+            assert a.size >= n and o.dtype == _C64 and o.flags.c_contiguous and o.size >= n
+        return check(lib.doa_antenna_correction_work(self._h, n, ptr_array([a.ctypes.data for a in ins]),
+                                                     ptr_array([o.ctypes.data for o in output_items])))
+
+    def work_dev(self, noutput_items, d_in_ptrs, d_out_ptrs, stream=None) -> int:
+        return check(lib.doa_antenna_correction_work_dev(self._h, int(noutput_items), ptr_array(d_in_ptrs),
+                                                         ptr_array(d_out_ptrs), _stream_ptr(stream)))
+
 
 class MUSIC_lin_array(_Block):
     """doa.MUSIC_lin_array(norm_spacing, num_targets, inputs, pspectrum_len) — gr::sync_block
@@ -221,6 +273,9 @@ class music_pipeline(_Block):
         self._h = check_handle(lib.doa_music_pipeline_create(self.inputs, self.snapshot_size, self.overlap_size,
                                                              self.avg_method, self.norm_spacing, self.num_targets,
                                                              self.pspectrum_len, self.max_batch), "music_pipeline")
+
+    def fuse_antenna_correction(self, correction) -> None:
+        _fuse(lib.doa_music_pipeline_fuse_antenna_correction, self._h, correction, self.inputs)
 
     def work_dev(self, noutput_items, d_input_ptrs, d_cov_ptr, d_spec_ptr, d_max_ptr, d_argmax_ptr, stream=None) -> int:
         return check(lib.doa_music_pipeline_work_dev(

@@ -106,6 +106,7 @@ class top_block:
         mno = self.max_noutput_items
         if hasattr(b, "general_work"):        # gr::block with history + forecast
             hist = b.history() - 1
+            in_arrays = [a.reshape(-1) for a in in_arrays]           # stream ports carry scalar items
             streams = [np.concatenate([np.zeros(hist, dtype=a.dtype), a]) for a in in_arrays]
             n_new = min(a.shape[0] for a in in_arrays)
             vlen = b.out_sig[0][1]
@@ -122,16 +123,17 @@ class top_block:
             if not chunks:
                 return [np.zeros((0, vlen), dtype=b.out_sig[0][0])]
             return [np.concatenate(chunks)]
-        # gr::sync_block
-        vlen_in = b.in_sig[0][1]
-        items = in_arrays[0].reshape(-1, vlen_in) if vlen_in > 1 else in_arrays[0].reshape(-1, 1)
-        total = items.shape[0]
+        # gr::sync_block (one or several input ports, all at the same rate)
+        ins = []
+        for a, (dt, vl) in zip(in_arrays, b.in_sig):
+            ins.append(a.reshape(-1, vl) if vl > 1 else a.reshape(-1, 1))
+        total = min(i.shape[0] for i in ins)
         outs = [[] for _ in b.out_sig]
         pos = 0
         while pos < total:
             n = min(mno, total - pos)
             bufs = [np.empty((n, vl), dtype=dt) for dt, vl in b.out_sig]
-            produced = b.work(n, [np.ascontiguousarray(items[pos:pos + n])], bufs)
+            produced = b.work(n, [np.ascontiguousarray(i[pos:pos + n]) for i in ins], bufs)
             for o, buf in zip(outs, bufs):
                 o.append(buf[:produced])
             pos += produced

@@ -7,10 +7,12 @@
 //   find_local_max          gr::sync_block, two outputs of vlen M (…/find_local_max_impl.cc:47-50)
 //   rootMUSIC_linear_array  gr::sync_block, io_signature(1, M, M floats), port 0 written
 //                           (…/rootMUSIC_linear_array_impl.cc:46-49,96)
+//   antenna_correction      gr::sync_block, N complex streams in/out (…/antenna_correction_impl.cc:47-52)
 // — and turn a failing ABI call into the behaviour a GNU Radio block has for it: constructors throw
 // std::runtime_error / std::invalid_argument (as antenna_correction_impl.cc:58-73 does), work()
 // returns WORK_DONE (-1) after logging, which stops the flowgraph.
 #include <doa/MUSIC_lin_array.h>
+#include <doa/antenna_correction.h>
 #include <doa/autocorrelate.h>
 #include <doa/find_local_max.h>
 #include <doa/rootMUSIC_linear_array.h>
@@ -139,8 +141,34 @@ public:
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+class antenna_correction_hip : public antenna_correction
+{
+    doa_antenna_correction_t *d_h;
+
+public:
+    antenna_correction_hip(int num_ant_ele, char *config_filename)
+        : gr::sync_block("antenna_correction", gr::io_signature::make(num_ant_ele, num_ant_ele, sizeof(gr_complex)),
+                         gr::io_signature::make(num_ant_ele, num_ant_ele, sizeof(gr_complex))),
+          d_h(doa_antenna_correction_create(num_ant_ele, config_filename))
+    {
+        // the reference throws std::invalid_argument for a bad configuration file (antenna_correction_impl.cc:58-73)
+        if (!d_h) throw std::invalid_argument(doa_last_error());
+    }
+    ~antenna_correction_hip() override { doa_antenna_correction_destroy(d_h); }
+    int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) override
+    {
+        const int produced = doa_antenna_correction_work(d_h, noutput_items, input_items.data(), output_items.data());
+        return produced < 0 ? work_failed("doa::antenna_correction", produced) : produced;
+    }
+};
+
 }  // namespace
 
+antenna_correction::sptr antenna_correction::make(int num_ant_ele, char *config_filename)
+{
+    return gnuradio::get_initial_sptr(new antenna_correction_hip(num_ant_ele, config_filename));
+}
 autocorrelate::sptr autocorrelate::make(int inputs, int snapshot_size, int overlap_size, int avg_method)
 {
     return gnuradio::get_initial_sptr(new autocorrelate_hip(inputs, snapshot_size, overlap_size, avg_method));

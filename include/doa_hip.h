@@ -170,6 +170,32 @@ DOA_HIP_API int doa_rootMUSIC_linear_array_work_dev(doa_rootMUSIC_linear_array_t
                                                     void *d_output_items0, void *hip_stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * antenna_correction — gr::doa::antenna_correction::make(num_ant_ele, config_filename)
+ *   (include/doa/antenna_correction.h:55, lib/antenna_correction_impl.cc:47-99).  gr::sync_block,
+ *   num_ant_ele gr_complex streams in and out: out_k[i] = g_k * in_k[i] with
+ *   g_k = (1/gain_k) * exp(-j phase_k) read from a text file with one "gain phase" pair per line.
+ *   create fails (message = the reference's std::invalid_argument text) when the file is missing
+ *   or has too many / too few lines.
+ * The block sits directly in front of autocorrelate; doa_autocorrelate_fuse_antenna_correction folds
+ * it into K1 (R[a,b] *= g_a conj(g_b) before the forward-backward step) so the corrected streams are
+ * never materialised.  (a "next" row beyond the north-star path.)
+ * --------------------------------------------------------------------------------------------- */
+typedef struct doa_antenna_correction doa_antenna_correction_t;
+
+DOA_HIP_API doa_antenna_correction_t *doa_antenna_correction_create(int num_ant_ele, const char *config_filename);
+DOA_HIP_API void doa_antenna_correction_destroy(doa_antenna_correction_t *h);
+/* Copies the num_ant_ele complex gains (re, im interleaved) out; returns num_ant_ele. */
+DOA_HIP_API int doa_antenna_correction_gains(const doa_antenna_correction_t *h, float *gains_re_im);
+DOA_HIP_API int doa_antenna_correction_work(doa_antenna_correction_t *h, int noutput_items,
+                                            const void *const *input_items, void *const *output_items);
+DOA_HIP_API int doa_antenna_correction_work_dev(doa_antenna_correction_t *h, int noutput_items,
+                                                const void *const *d_input_items, void *const *d_output_items,
+                                                void *hip_stream);
+/* Fold a per-stream complex gain into this autocorrelate handle (gains_re_im: inputs pairs, or NULL
+ * to remove it).  Equivalent to an antenna_correction block feeding the autocorrelate block. */
+DOA_HIP_API int doa_autocorrelate_fuse_antenna_correction(doa_autocorrelate_t *h, const float *gains_re_im);
+
+/* ---------------------------------------------------------------------------------------------
  * music_pipeline — autocorrelate -> MUSIC_lin_array -> find_local_max(num_targets, pspectrum_len,
  *   0, 180) on device-resident streams, the batch entry point the benchmark drives
  *   (apps/run_MUSIC_lin_array_simulation.grc wiring).  All pointers are DEVICE pointers except
@@ -183,6 +209,8 @@ DOA_HIP_API doa_music_pipeline_t *doa_music_pipeline_create(int inputs, int snap
                                                             float norm_spacing, int num_targets,
                                                             int pspectrum_len, int max_batch);
 DOA_HIP_API void doa_music_pipeline_destroy(doa_music_pipeline_t *h);
+/* Same fusion as doa_autocorrelate_fuse_antenna_correction, for the pipeline's K1. */
+DOA_HIP_API int doa_music_pipeline_fuse_antenna_correction(doa_music_pipeline_t *h, const float *gains_re_im);
 DOA_HIP_API int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput_items,
                                             const void *const *d_input_items, void *d_cov_out,
                                             void *d_spectrum_out, void *d_max_out,

@@ -38,6 +38,41 @@ _C64 = np.complex64
 
 
 # --------------------------------------------------------------------------------------------
+# antenna_correction  (lib/antenna_correction_impl.cc) — the block in front of autocorrelate
+# --------------------------------------------------------------------------------------------
+def antenna_correction_gains(config_text: str, num_ant_ele: int) -> np.ndarray:
+    """Constructor of doa::antenna_correction.  lib/antenna_correction_impl.cc:56-73: the file is read
+    with `infile >> GainEst >> PhaseEst` (whitespace-separated floats, stops at the first token that
+    does not parse); g_k = gr_complex(1.0/GainEst, 0) * exp(gr_complex(0, -PhaseEst)); more than
+    num_ant_ele pairs / fewer -> std::invalid_argument."""
+    tokens = config_text.split()
+    vals = []
+    for tok in tokens:
+        try:
+            vals.append(_F32(float(tok)))
+        except ValueError:
+            break
+    pairs = len(vals) // 2
+    if pairs > num_ant_ele:
+        raise ValueError("Configuration file has too many inputs.")
+    if pairs != num_ant_ele:
+        raise ValueError("Configuration file does not have enough inputs.")
+    g = np.empty(num_ant_ele, dtype=_C64)
+    for k in range(num_ant_ele):
+        gain, phase = vals[2 * k], vals[2 * k + 1]
+        a = _F32(1.0 / float(gain))                                   # double division -> float
+        e = _C64(complex(np.cos(_F32(-phase), dtype=_F32), np.sin(_F32(-phase), dtype=_F32)))   # exp(complex<float>(0,-p))
+        g[k] = _C64(_C64(complex(a, 0.0)) * e)
+    return g
+
+
+def antenna_correction(input_items: np.ndarray, gains: np.ndarray) -> np.ndarray:
+    """work(): out_k[i] = g_k * in_k[i] in complex<float>.  lib/antenna_correction_impl.cc:85-99."""
+    x = np.asarray(input_items, dtype=_C64)
+    return (np.asarray(gains, dtype=_C64)[:, None] * x).astype(_C64)
+
+
+# --------------------------------------------------------------------------------------------
 # autocorrelate  (lib/autocorrelate_impl.cc)
 # --------------------------------------------------------------------------------------------
 def gr_history_prepend(streams: np.ndarray, overlap_size: int) -> np.ndarray:
