@@ -25,6 +25,11 @@ EXPECT = {
         params={"num_max_vals": "1", "vector_len": "2**9", "x_min": "0.0", "x_max": "180.0"},
         checks=["$num_max_vals > 0", "$vector_len > 0", "$x_max > $x_min"],
         sinks=[("float", "$vector_len", None)], sources=[("float", "$num_max_vals", None), ("float", "$num_max_vals", None)]),
+    "doa_antenna_correction": dict(
+        make="doa.antenna_correction($num_inputs, $config_filename)",
+        params={"num_inputs": None, "config_filename": "/tmp/antenna.cfg"},
+        checks=[],
+        sinks=[("complex", None, "$num_inputs")], sources=[("complex", None, "$num_inputs")]),
     "doa_rootMUSIC_linear_array": dict(
         make="doa.rootMUSIC_linear_array($norm_spacing, $num_targets, $inputs)",
         params={"norm_spacing": "0.5", "num_targets": "1", "inputs": "1"},
