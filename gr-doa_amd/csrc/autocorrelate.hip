@@ -9,9 +9,9 @@
 // Kernel shape (HBM-bound, ~1 flop/B): one 64-lane wave owns one snapshot.  Each lane streams
 // 16-byte (two-sample) loads from every channel — a wave instruction covers 1 KiB contiguous per
 // channel — and keeps the Hermitian upper triangle (N real + N(N-1)/2 complex partial sums) in
-// registers; partials meet in one wave all-reduce and lanes 0..N^2-1 write the 8N^2-byte item
+// registers; partials meet in one DPP wave all-reduce and lanes 0..N^2-1 write the 8N^2-byte item
 // as one contiguous segment.  No LDS, no atomics; with overlapping windows the re-read halo is
-// served by L2.  N > 8 runs as 8x8 channel tiles of the same loop.
+// served by L2.  8 < N <= 16 runs on the matrix cores (cov_mfma_kernel).
 #include "common.hpp"
 
 #include <cstdlib>
@@ -28,7 +28,6 @@ struct CovArgs {
     int avg;       // 1 = forward-backward
     float inv_k;   // (float)(1.0/K)
     float fb_hk;   // (float)(0.5/K)
-    int a0, b0;    // tile origin (tile kernel only)
     const float2 *gain;   // optional [N*N] g_a conj(g_b) (fused antenna_correction), or nullptr
 };
 
@@ -161,88 +160,6 @@ __global__ __launch_bounds__(256) void cov_wave_kernel(CovArgs g)
     }
     if (lane < TN * TN) g.out[(size_t)snap * (TN * TN) + lane] = r;
     }  // snapshot loop
-}
-
-// 8x8 channel tile of a wider array (8 < N <= 16): rows a0.., columns b0.. ; channels past N
-// alias channel 0 on the load side and are masked on the store side.  Off-diagonal tiles also
-// write the mirrored conjugate block.  FB averaging is applied afterwards by cov_fb_kernel.
-template <bool VEC2> __global__ __launch_bounds__(256) void cov_tile_kernel(CovArgs g)
-{
-    constexpr int T = 8;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int snap = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
-    if (snap >= g.n_out) return;
-    const size_t base = (size_t)snap * (size_t)g.S;
-    const float2 *pa[T], *pb[T];
-#pragma unroll
-    for (int i = 0; i < T; i++) {
-        pa[i] = g.in[(g.a0 + i < g.n_ch) ? g.a0 + i : 0] + base;
-        pb[i] = g.in[(g.b0 + i < g.n_ch) ? g.b0 + i : 0] + base;
-    }
-    float re[T][T], im[T][T];
-#pragma unroll
-    for (int a = 0; a < T; a++)
-#pragma unroll
-        for (int b = 0; b < T; b++) { re[a][b] = 0.f; im[a][b] = 0.f; }
-
-    auto mac = [&](const float2 (&xa)[T], const float2 (&xb)[T]) {
-#pragma unroll
-        for (int a = 0; a < T; a++)
-#pragma unroll
-            for (int b = 0; b < T; b++) {
-                re[a][b] = fmaf(xa[a].x, xb[b].x, fmaf(xa[a].y, xb[b].y, re[a][b]));
-                im[a][b] = fmaf(xa[a].y, xb[b].x, fmaf(-xa[a].x, xb[b].y, im[a][b]));
-            }
-    };
-    if constexpr (VEC2) {
-        const int npair = g.K >> 1;
-        for (int p = lane; p < npair; p += kWave) {
-            float2 xa0[T], xa1[T], xb0[T], xb1[T];
-#pragma unroll
-            for (int i = 0; i < T; i++) {
-                float4 va = *reinterpret_cast<const float4 *>(pa[i] + 2 * (size_t)p);
-                float4 vb = *reinterpret_cast<const float4 *>(pb[i] + 2 * (size_t)p);
-                xa0[i] = make_float2(va.x, va.y); xa1[i] = make_float2(va.z, va.w);
-                xb0[i] = make_float2(vb.x, vb.y); xb1[i] = make_float2(vb.z, vb.w);
-            }
-            mac(xa0, xb0);
-            mac(xa1, xb1);
-        }
-        if ((g.K & 1) && lane == 0) {
-            float2 xa[T], xb[T];
-#pragma unroll
-            for (int i = 0; i < T; i++) { xa[i] = pa[i][g.K - 1]; xb[i] = pb[i][g.K - 1]; }
-            mac(xa, xb);
-        }
-    } else {
-        for (int t = lane; t < g.K; t += kWave) {
-            float2 xa[T], xb[T];
-#pragma unroll
-            for (int i = 0; i < T; i++) { xa[i] = pa[i][t]; xb[i] = pb[i][t]; }
-            mac(xa, xb);
-        }
-    }
-    float2 r = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int a = 0; a < T; a++)
-#pragma unroll
-        for (int b = 0; b < T; b++) {
-            const float sr = wave_allreduce_sum(re[a][b]);
-            const float si = wave_allreduce_sum(im[a][b]);
-            if (lane == a + b * T) r = make_float2(sr, si);
-        }
-    r.x = __fmul_rn(r.x, g.inv_k);
-    r.y = __fmul_rn(r.y, g.inv_k);
-    const int a = g.a0 + (lane & (T - 1)), b = g.b0 + (lane >> 3);
-    if (a < g.n_ch && b < g.n_ch) {
-        if (g.gain) {
-            const float2 w = g.gain[a + b * g.n_ch];
-            r = make_float2(fmaf(w.x, r.x, -w.y * r.y), fmaf(w.x, r.y, w.y * r.x));
-        }
-        float2 *item = g.out + (size_t)snap * g.n_ch * g.n_ch;
-        item[a + (size_t)b * g.n_ch] = r;
-        if (g.a0 != g.b0) item[b + (size_t)a * g.n_ch] = make_float2(r.x, -r.y);
-    }
 }
 
 // Wide arrays (8 < N <= 16): the per-snapshot outer-product sum is a 16 x K by K x 16 complex GEMM,
@@ -410,21 +327,10 @@ int launch_autocorrelate(int N, int K, int ovl, int avg, int n_out, const void *
     case 7: launch_wave<7>(g, vec2, st); break;
     case 8: launch_wave<8>(g, vec2, st); break;
     default: {
-        static const int use_tiles = [] { const char *e = getenv("DOA_COV_TILES"); return e ? atoi(e) : 0; }();
-        if (use_tiles) {                 // VALU 8x8 register tiles (kept for A/B against the MFMA kernel)
-            dim3 grid((n_out + 3) / 4), block(256);
-            for (int a0 = 0; a0 < N; a0 += 8)
-                for (int b0 = a0; b0 < N; b0 += 8) {
-                    g.a0 = a0; g.b0 = b0;
-                    if (vec2) hipLaunchKernelGGL(cov_tile_kernel<true>, grid, block, 0, st, g);
-                    else      hipLaunchKernelGGL(cov_tile_kernel<false>, grid, block, 0, st, g);
-                }
-        } else {
-            int blocks = (n_out + 3) / 4;
-            if (blocks > 256 * 4) blocks = 256 * 4;        // <= 16 waves per CU, grid-stride beyond
-            if (vec2) hipLaunchKernelGGL(cov_mfma_kernel<true>, dim3(blocks), dim3(256), 0, st, g);
-            else      hipLaunchKernelGGL(cov_mfma_kernel<false>, dim3(blocks), dim3(256), 0, st, g);
-        }
+        int blocks = (n_out + 3) / 4;
+        if (blocks > 256 * 4) blocks = 256 * 4;        // <= 16 waves per CU, grid-stride beyond
+        if (vec2) hipLaunchKernelGGL(cov_mfma_kernel<true>, dim3(blocks), dim3(256), 0, st, g);
+        else      hipLaunchKernelGGL(cov_mfma_kernel<false>, dim3(blocks), dim3(256), 0, st, g);
         if (avg == 1) {
             const int nn = N * N, half = (nn + 1) / 2;
             const long long total = (long long)n_out * half;

@@ -7,9 +7,10 @@
 //                        -> P_N = U_N U_N^H -> out[i] = 1/Re(a_i^H P_N a_i) -> 10 log10(out/max)
 //
 // How it is laid out here:
-//   * EVD (music_evd_kernel): one lane per covariance matrix.  Cyclic complex Jacobi on the full
-//     Hermitian matrix held in registers (N <= 4, fully unrolled) or per-lane scratch (N <= 16),
-//     in double by default (float selectable: doa_set_evd_precision).  Rotations are built from
+//   * EVD: cyclic complex Jacobi, in double by default (float selectable:
+//     doa_set_internal_precision).  N <= 4 (music_evd_kernel): one lane per covariance matrix, diagonal +
+//     strict upper triangle and V in registers, fully unrolled.  N > 4 (music_evd_group_kernel): 8 or 16
+//     lanes per matrix, one row of A and V per lane, round-robin parallel ordering.  Rotations are built from
 //     rsqrt only, so J is unitary to working precision.  Epilogue: rank eigenvalues ascending,
 //     P_N = sum over the N-M smallest of v v^H, and the 2N-1 diagonal sums
 //         u_l = sum_r P_N[r+l, r]   (u_0 real, u_l complex)
@@ -283,160 +284,228 @@ __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// N > 4: the same Jacobi with the matrices in LDS instead of registers.  One lane per item still
-// (no barriers: a lane only ever touches its own column of the [element][lane] LDS image, which is
-// also bank-conflict free), but A's packed upper triangle, V and the result scratch live in LDS
-// where run-time row/column indices cost nothing; 3N^2+3N values per item bound the lanes per
-// block (double: 64 lanes at N = 8, 25 at N = 16, one block per CU).
+// Group-parallel Jacobi: G lanes (G = 4, 8 or 16 >= N) share one item.  Lane r of the group holds
+// row r of A and row r of V in registers; a sweep is the G-1 rounds of a round-robin tournament,
+// each round rotating G/2 disjoint pivot pairs at once:
+//   * every lane builds the rotation of its own pair from (A[r][r], A[q][q], A[r][q]), q = its
+//     partner this round (partner diagonal: one cross-lane fetch);
+//   * A <- A J and V <- V J are column operations, i.e. lane-local, with compile-time column pairs
+//     (rounds are unrolled) and the pair parameters broadcast from the owning lane;
+//   * A <- J^H A mixes row r with the partner's row: one cross-lane fetch of that row.
+// 4 (G = 16) to 16 (G = 4) items per wave instead of 64, but the dependent instruction chain per item
+// shrinks by ~G/2 and there is no run-time register indexing, LDS image or scratch.
+// Indices >= N are padding: zero off-diagonals and a huge diagonal, so they never rotate and rank
+// last.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(64) void music_evd_lds_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
-                                                           double *__restrict__ coef_d, float2 *__restrict__ pn_out,
-                                                           int n_items, int N, int M, int LB)
+template <int G> struct Tournament {
+    // pair j of round t of the circle method on G players: (G-1, t) and ((t+k) % (G-1), (t-k) % (G-1))
+    static constexpr int a(int t, int j) { return j == 0 ? G - 1 : (t + j) % (G - 1); }
+    static constexpr int b(int t, int j) { return j == 0 ? t : (t - j + (G - 1)) % (G - 1); }
+    static constexpr int p(int t, int j) { return a(t, j) < b(t, j) ? a(t, j) : b(t, j); }
+    static constexpr int q(int t, int j) { return a(t, j) < b(t, j) ? b(t, j) : a(t, j); }
+};
+
+template <typename T> __device__ __forceinline__ T lane_fetch(T v, int src_lane);
+template <> __device__ __forceinline__ float lane_fetch<float>(float v, int src_lane) { return __shfl(v, src_lane, kWave); }
+template <> __device__ __forceinline__ double lane_fetch<double>(double v, int src_lane) { return __shfl(v, src_lane, kWave); }
+
+// sum over the G lanes of a group (G = 4, 8, 16; groups are aligned inside a DPP row of 16)
+template <int G, typename T> __device__ __forceinline__ T group_sum(T v, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *sm = reinterpret_cast<T *>(smem_raw);
-    const int lane = threadIdx.x;
-    const int item = blockIdx.x * LB + lane;
-    if (lane >= LB || item >= n_items) return;
-    const int NT = N * (N - 1) / 2;
-    // LDS image, element-major: dg[N] | ur[NT] | ui[NT] | vr[N*N] | vi[N*N] | cu_r[N] | cu_i[N]
-    auto at = [&](int e) -> T & { return sm[(size_t)e * LB + lane]; };
-    const int oDG = 0, oUR = N, oUI = N + NT, oVR = N + 2 * NT, oVI = oVR + N * N, oCR = oVI + N * N, oCI = oCR + N;
-    auto tri = [&](int r, int c) { return r * N - r * (r + 1) / 2 + (c - r - 1); };   // r < c
-
-    const float2 *Ri = R + (size_t)item * (N * N);
-    for (int c = 0; c < N; c++)
-        for (int r = 0; r <= c; r++) {
-            const float2 x = Ri[r + c * N];
-            if (r == c) at(oDG + r) = (T)x.x;
-            else { at(oUR + tri(r, c)) = (T)x.x; at(oUI + tri(r, c)) = (T)x.y; }
-        }
-    for (int r = 0; r < N; r++)
-        for (int c = 0; c < N; c++) { at(oVR + r * N + c) = (r == c) ? (T)1 : (T)0; at(oVI + r * N + c) = 0; }
-
-    const int max_sweeps = Real<T>::max_sweeps + 2 * N;
-    for (int sweep = 0; sweep < max_sweeps; sweep++) {
-        T off = 0, dn = 0;
-        for (int p = 0; p < N; p++) dn = fma(at(oDG + p), at(oDG + p), dn);
-        for (int e = 0; e < NT; e++) off += at(oUR + e) * at(oUR + e) + at(oUI + e) * at(oUI + e);
-        if (!(off > Real<T>::tol * dn) || !(off > Real<T>::tiny)) break;
-        for (int p = 0; p < N - 1; p++) {
-            for (int q = p + 1; q < N; q++) {
-                const int epq = tri(p, q);
-                const T apr = at(oUR + epq), api = at(oUI + epq);
-                const T g2 = apr * apr + api * api;
-                if (!(g2 > Real<T>::tiny)) continue;
-                const T inv_g = Real<T>::rsqrt(g2);
-                const T g = g2 * inv_g;
-                const T phr = apr * inv_g, phi = api * inv_g;
-                const T app = at(oDG + p), aqq = at(oDG + q);
-                T tau = (aqq - app) * (T)0.5 * inv_g;
-                tau = fmin(fmax(tau, -Real<T>::tau_max), Real<T>::tau_max);
-                const T x1 = fma(tau, tau, (T)1);
-                const T r = x1 * Real<T>::rsqrt(x1);
-                const T h = fabs(tau) + r;
-                const T w = Real<T>::rsqrt(fma(h, h, (T)1));
-                const T c = h * w;
-                const T s = copysign(w, tau);
-                const T spr = s * phr, spi = s * phi;
-                const T cc = c * c, ss = s * s, csg = (T)2 * c * s * g;
-                at(oDG + p) = fma(cc, app, fma(ss, aqq, -csg));
-                at(oDG + q) = fma(ss, app, fma(cc, aqq, csg));
-                at(oUR + epq) = 0; at(oUI + epq) = 0;
-                for (int k = 0; k < N; k++) {
-                    if (k == p || k == q) continue;
-                    const int ekp = (k < p) ? tri(k, p) : tri(p, k);
-                    const int ekq = (k < q) ? tri(k, q) : tri(q, k);
-                    const T sgp = (k < p) ? (T)1 : (T)-1, sgq = (k < q) ? (T)1 : (T)-1;   // conj when stored transposed
-                    const T xr = at(oUR + ekp), xi = sgp * at(oUI + ekp);
-                    const T yr = at(oUR + ekq), yi = sgq * at(oUI + ekq);
-                    const T nxr = c * xr - (spr * yr + spi * yi);
-                    const T nxi = c * xi - (spr * yi - spi * yr);
-                    const T nyr = c * yr + (spr * xr - spi * xi);
-                    const T nyi = c * yi + (spr * xi + spi * xr);
-                    at(oUR + ekp) = nxr; at(oUI + ekp) = sgp * nxi;
-                    at(oUR + ekq) = nyr; at(oUI + ekq) = sgq * nyi;
-                }
-                for (int k = 0; k < N; k++) {
-                    const T kpr = at(oVR + k * N + p), kpi = at(oVI + k * N + p);
-                    const T kqr = at(oVR + k * N + q), kqi = at(oVI + k * N + q);
-                    at(oVR + k * N + p) = c * kpr - (spr * kqr + spi * kqi);
-                    at(oVI + k * N + p) = c * kpi - (spr * kqi - spi * kqr);
-                    at(oVR + k * N + q) = c * kqr + (spr * kpr - spi * kpi);
-                    at(oVI + k * N + q) = c * kqi + (spr * kpi + spi * kpr);
-                }
-            }
-        }
-    }
-    // noise set: ascending rank < N-M (bit i of sel)
-    unsigned sel = 0;
-    for (int i = 0; i < N; i++) {
-        int rank = 0;
-        const T wi = at(oDG + i);
-        for (int j = 0; j < N; j++) {
-            const T wj = at(oDG + j);
-            rank += ((wj < wi) || (wj == wi && j < i)) ? 1 : 0;
-        }
-        if (rank < N - M) sel |= 1u << i;
-    }
-    for (int l = 0; l < N; l++) { at(oCR + l) = 0; at(oCI + l) = 0; }
-    float2 *po = pn_out ? pn_out + (size_t)item * (N * N) : nullptr;
-    for (int a = 0; a < N; a++)
-        for (int b = a; b < N; b++) {
-            T pr = 0, pi = 0;
-            for (int i = 0; i < N; i++)
-                if ((sel >> i) & 1u) {
-                    const T ar_ = at(oVR + a * N + i), ai_ = at(oVI + a * N + i);
-                    const T br_ = at(oVR + b * N + i), bi_ = at(oVI + b * N + i);
-                    pr = fma(ar_, br_, fma(ai_, bi_, pr));
-                    pi = fma(ai_, br_, fma(-ar_, bi_, pi));
-                }
-            // u_l = sum_r P[r+l][r] = conj(sum_r P[r][r+l])
-            at(oCR + (b - a)) += pr;
-            at(oCI + (b - a)) -= pi;
-            if (po) {
-                po[a + b * N] = make_float2((float)pr, (float)pi);
-                if (a != b) po[b + a * N] = make_float2((float)pr, -(float)pi);
-            }
-        }
-    float *co = coef ? coef + (size_t)item * (2 * N) : nullptr;
-    double *cd = coef_d ? coef_d + (size_t)item * (2 * N) : nullptr;
-    for (int l = 0; l < N; l++) {
-        const T ur_ = at(oCR + l), ui_ = at(oCI + l);
-        if (l == 0) {
-            if (co) co[0] = (float)ur_;
-            if (cd) cd[0] = (double)ur_;
-        } else {
-            if (co) { co[2 * l - 1] = (float)ur_; co[2 * l] = (float)ui_; }
-            if (cd) { cd[2 * l - 1] = (double)ur_; cd[2 * l] = (double)ui_; }
-        }
-    }
-    if (co) co[2 * N - 1] = 0.f;
-    if (cd) cd[2 * N - 1] = 0.0;
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) v += lane_fetch<T>(v, lane ^ m);
+    return v;
 }
 
-template <typename T>
-static int launch_evd_lds(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
-                          hipStream_t st)
+template <int G, typename T, int ROUND>
+__device__ __forceinline__ void jacobi_round(T (&ar)[G], T (&ai)[G], T (&vr)[G], T (&vi)[G], int r, int base, bool active)
 {
-    const size_t per_item = (size_t)(3 * N * N + 3 * N) * sizeof(T);   // generous bound on the LDS image
-    const size_t budget = 156 * 1024;
-    int LB = (int)(budget / per_item);
-    if (LB > 64) LB = 64;
-    if (LB < 1) { set_error("MUSIC: LDS image of one %dx%d item does not fit", N, N); return DOA_ERR_UNSUPPORTED; }
-    const size_t bytes = per_item * LB;
-    static size_t configured_f = 0, configured_d = 0;
-    size_t &configured = (sizeof(T) == 4) ? configured_f : configured_d;
-    if (bytes > configured) {
-        DOA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&music_evd_lds_kernel<T>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        configured = 160 * 1024;
+    using TT = Tournament<G>;
+    // partner of lane r in this round
+    const int partner = (r == G - 1) ? ROUND : ((r == ROUND) ? G - 1 : (2 * ROUND - r + 2 * (G - 1)) % (G - 1));
+    // own diagonal, partner diagonal, pivot element A[r][partner]
+    T d_own = 0, xr = 0, xi = 0;
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        d_own = (k == r) ? ar[k] : d_own;
+        xr = (k == partner) ? ar[k] : xr;
+        xi = (k == partner) ? ai[k] : xi;
     }
-    dim3 block(64), grid((n_items + LB - 1) / LB);
-    hipLaunchKernelGGL((music_evd_lds_kernel<T>), grid, block, bytes, st, (const float2 *)d_R, (float *)d_coef,
-                       (double *)d_coef_d, (float2 *)d_pn, n_items, N, M, LB);
-    return DOA_OK;
+    const T d_oth = lane_fetch<T>(d_own, base + partner);
+    const T g2 = xr * xr + xi * xi;
+    const bool live = active && (g2 > Real<T>::tiny);
+    const T inv_g = Real<T>::rsqrt(live ? g2 : (T)1);
+    const T phr = xr * inv_g, phi = xi * inv_g;
+    T tau = (d_oth - d_own) * (T)0.5 * inv_g;
+    tau = fmin(fmax(tau, -Real<T>::tau_max), Real<T>::tau_max);
+    const T x1 = fma(tau, tau, (T)1);
+    const T rt = x1 * Real<T>::rsqrt(x1);
+    const T h = fabs(tau) + rt;
+    const T w = Real<T>::rsqrt(fma(h, h, (T)1));
+    // Both lanes of a pair evaluate this, but only the lower lane's result is used (below): its
+    // partner sees A[q][p], which equals conj(A[p][q]) only to rounding, and two almost-equal
+    // rotations are not one unitary rotation once the pivot has shrunk to that level.
+    const T c_mine = live ? h * w : (T)1;
+    const T s_mine = live ? copysign(w, tau) : (T)0;
+    const int lo = (r < partner) ? r : partner;
+    const T c = lane_fetch<T>(c_mine, base + lo);
+    const T slr = lane_fetch<T>(s_mine * phr, base + lo), sli = lane_fetch<T>(s_mine * phi, base + lo);   // sigma = J[lo][hi]
+    const T sgr = (r == lo) ? slr : -slr, sgi = (r == lo) ? sli : sli;    // J[r][partner]: sigma, or -conj(sigma)
+    // column operations A <- A J, V <- V J: canonical (c, sigma) of each pair come from its lower lane
+#pragma unroll
+    for (int j = 0; j < G / 2; j++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int P = TT::p(ROUND, j), Q = TT::q(ROUND, j);
+        const T cj = lane_fetch<T>(c, base + P);
+        const T sr = lane_fetch<T>(sgr, base + P), si = lane_fetch<T>(sgi, base + P);
+        {
+            const T pr = ar[P], pi = ai[P], qr = ar[Q], qi = ai[Q];
+            ar[P] = cj * pr - (sr * qr + si * qi);
+            ai[P] = cj * pi - (sr * qi - si * qr);
+            ar[Q] = cj * qr + (sr * pr - si * pi);
+            ai[Q] = cj * qi + (sr * pi + si * pr);
+        }
+        {
+            const T pr = vr[P], pi = vi[P], qr = vr[Q], qi = vi[Q];
+            vr[P] = cj * pr - (sr * qr + si * qi);
+            vi[P] = cj * pi - (sr * qi - si * qr);
+            vr[Q] = cj * qr + (sr * pr - si * pi);
+            vi[Q] = cj * qi + (sr * pi + si * pr);
+        }
+    }
+    // row operation A <- J^H A: row_r' = c row_r - sigma_r row_partner (same form on both lanes of a pair)
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        const T orr = lane_fetch<T>(ar[k], base + partner), oi = lane_fetch<T>(ai[k], base + partner);
+        const T nr = c * ar[k] - (sgr * orr - sgi * oi);
+        const T ni = c * ai[k] - (sgr * oi + sgi * orr);
+        ar[k] = nr; ai[k] = ni;
+    }
+}
+
+template <int G, typename T, int ROUND> struct RoundLoop {
+    static __device__ __forceinline__ void run(T (&ar)[G], T (&ai)[G], T (&vr)[G], T (&vi)[G], int r, int base, bool active)
+    {
+        jacobi_round<G, T, ROUND>(ar, ai, vr, vi, r, base, active);
+        if constexpr (ROUND + 1 < G - 1) RoundLoop<G, T, ROUND + 1>::run(ar, ai, vr, vi, r, base, active);
+    }
+};
+
+template <int G, typename T>
+__global__ __launch_bounds__(64) void music_evd_group_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
+                                                             double *__restrict__ coef_d, float2 *__restrict__ pn_out,
+                                                             int n_items, int N, int M)
+{
+    constexpr int IPW = kWave / G;                       // items per wave
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r = lane % G, base = lane - r;
+    int item = blockIdx.x * IPW + lane / G;
+    const bool real_item = item < n_items;
+    if (!real_item) item = n_items - 1;                  // idle groups shadow the last item (no stores)
+    const float2 *Ri = R + (size_t)item * (N * N);
+
+    T ar[G], ai[G], vr[G], vi[G];
+#pragma unroll
+    for (int c = 0; c < G; c++) {
+        T xr = 0, xi = 0;
+        if (r < N && c < N) {
+            // upper triangle only (cheevd uplo='U'): A[r][c] = R[r + c N] for r <= c, else conj(R[c + r N])
+            const float2 x = (r <= c) ? Ri[r + c * N] : Ri[c + r * N];
+            xr = (T)x.x;
+            xi = (r == c) ? (T)0 : ((r < c) ? (T)x.y : -(T)x.y);
+        } else if (r == c) {
+            xr = (T)1e30;                                // padding: isolated, ranks after every real eigenvalue
+        }
+        ar[c] = xr; ai[c] = xi;
+        vr[c] = (r == c) ? (T)1 : (T)0; vi[c] = 0;
+    }
+    const int max_sweeps = Real<T>::max_sweeps + G;
+    bool active = true;
+    for (int sweep = 0; sweep < max_sweeps; sweep++) {
+        T off = 0, dn = 0;
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const T m = ar[k] * ar[k] + ai[k] * ai[k];
+            if (r < N && k < N) { if (k == r) dn += m; else off += m; }
+        }
+        off = group_sum<G, T>(off, lane);
+        dn = group_sum<G, T>(dn, lane);
+        active = active && (off > Real<T>::tol * dn) && (off > Real<T>::tiny);
+        if (!__any(active)) break;
+        RoundLoop<G, T, 0>::run(ar, ai, vr, vi, r, base, active);
+    }
+    // eigenvalue of lane r = A[r][r]; ascending rank inside the group; noise set = ranks < N-M
+    T lam = 0;
+#pragma unroll
+    for (int k = 0; k < G; k++) lam = (k == r) ? ar[k] : lam;
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+        const T lj = lane_fetch<T>(lam, base + j);
+        rank += ((lj < lam) || (lj == lam && j < r)) ? 1 : 0;
+    }
+    const bool is_noise = (r < N) && (rank < N - M);
+    const unsigned long long noise_mask = __ballot(is_noise);
+    const unsigned sel = (unsigned)((noise_mask >> base) & ((1ull << G) - 1ull));     // bit i: column i is a noise vector
+    // masked columns: Y = V S
+    T yr[G], yi[G];
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+        const bool on = (sel >> i) & 1u;
+        yr[i] = on ? vr[i] : (T)0; yi[i] = on ? vi[i] : (T)0;
+    }
+    if (pn_out) {                                         // diagnostics: P_N[r][b] = sum_i Y[r][i] conj(V[b][i])
+        float2 *po = pn_out + (size_t)item * (N * N);
+        for (int b = 0; b < N; b++) {
+            T pr = 0, pi = 0;
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                const T br = lane_fetch<T>(vr[i], base + b), bi = lane_fetch<T>(vi[i], base + b);
+                pr = fma(yr[i], br, fma(yi[i], bi, pr));
+                pi = fma(yi[i], br, fma(-yr[i], bi, pi));
+            }
+            if (real_item && r < N) po[r + b * N] = make_float2((float)pr, (float)pi);
+        }
+    }
+    // u_l = sum_r P_N[r+l][r] = sum_r sum_i Y[r+l][i] conj(V[r][i]): fetch row r+l, dot with own row, reduce
+    float *co = (coef && real_item) ? coef + (size_t)item * (2 * N) : nullptr;
+    double *cd = (coef_d && real_item) ? coef_d + (size_t)item * (2 * N) : nullptr;
+    for (int l = 0; l < N; l++) {
+        T tr = 0, ti = 0;
+        const int src = (r + l < G) ? base + r + l : lane;
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const T ur = lane_fetch<T>(yr[i], src), ui = lane_fetch<T>(yi[i], src);
+            tr = fma(ur, vr[i], fma(ui, vi[i], tr));
+            ti = fma(ui, vr[i], fma(-ur, vi[i], ti));
+        }
+        if (!(r + l < N)) { tr = 0; ti = 0; }
+        tr = group_sum<G, T>(tr, lane);
+        ti = group_sum<G, T>(ti, lane);
+        if (r == 0) {
+            if (l == 0) {
+                if (co) co[0] = (float)tr;
+                if (cd) cd[0] = (double)tr;
+            } else {
+                if (co) { co[2 * l - 1] = (float)tr; co[2 * l] = (float)ti; }
+                if (cd) { cd[2 * l - 1] = (double)tr; cd[2 * l] = (double)ti; }
+            }
+        }
+    }
+    if (r == 0) {
+        if (co) co[2 * N - 1] = 0.f;
+        if (cd) cd[2 * N - 1] = 0.0;
+    }
+}
+
+template <int G, typename T>
+static void launch_evd_group(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
+                             hipStream_t st)
+{
+    constexpr int IPW = kWave / G;
+    dim3 block(64), grid((n_items + IPW - 1) / IPW);
+    hipLaunchKernelGGL((music_evd_group_kernel<G, T>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,
+                       (double *)d_coef_d, (float2 *)d_pn, n_items, N, M);
 }
 
 template <int N> static void launch_evd_n(int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
@@ -459,15 +528,27 @@ int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, v
         set_error("MUSIC: num_ant_ele=%d outside the built range 2..%d", N, DOA_MAX_ANT_ELE);
         return DOA_ERR_UNSUPPORTED;
     }
-    switch (N) {
-    case 2: launch_evd_n<2>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
-    case 3: launch_evd_n<3>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
-    case 4: launch_evd_n<4>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
-    default: {
-        const int rc = (evd_bits == 32) ? launch_evd_lds<float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st)
-                                        : launch_evd_lds<double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
-        if (rc != DOA_OK) return rc;
-    }
+    // N <= 4: one lane per item, everything in registers (measured 10.5 us vs 11.0 us for the
+    // 4-lane group kernel at batch 4096: at this size the cross-lane traffic eats the shorter
+    // dependency chain).  N > 4: 8 or 16 lanes per item (15x / 17x faster than one lane per item with
+    // the matrices in scratch).  DOA_EVD_KERNEL=1 forces the group kernel for N <= 4 (A/B runs).
+    static const int force_group = [] { const char *e = getenv("DOA_EVD_KERNEL"); return e ? atoi(e) : 0; }();
+    const bool f32 = (evd_bits == 32);
+    if (N > 8) {
+        if (f32) launch_evd_group<16, float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
+        else launch_evd_group<16, double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
+    } else if (N > 4) {
+        if (f32) launch_evd_group<8, float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
+        else launch_evd_group<8, double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
+    } else if (force_group == 1) {
+        if (f32) launch_evd_group<4, float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
+        else launch_evd_group<4, double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
+    } else {
+        switch (N) {
+        case 2: launch_evd_n<2>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
+        case 3: launch_evd_n<3>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
+        default: launch_evd_n<4>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
+        }
     }
     DOA_HIP_TRY(hipGetLastError());
     return DOA_OK;
