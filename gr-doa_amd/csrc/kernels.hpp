@@ -27,6 +27,8 @@ inline int coef_stride(int N) { return 2 * N; }
 // scan), d_coef_d (double records, same layout, for the root finder) and d_pn may each be NULL.
 int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
                      int evd_bits, hipStream_t st);
+// calibrate_lin_array (calibrate.hip): d_pilot = N float2 (pilot steering vector), d_out = n_items*N float2
+int launch_calibrate(int N, int n_items, const void *d_R, const void *d_pilot, void *d_out, int bits, hipStream_t st);
 // K4: spectrum scan in float (bits == 32, float coefficient records) or double (bits == 64, double
 // records).  d_q (un-normalised null spectrum, P floats per item) may be NULL.
 // With `peaks` (+ d_max/d_argmax) the find_local_max step is fused into the scan when the fast path

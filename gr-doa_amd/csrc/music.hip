@@ -394,7 +394,8 @@ template <int G, typename T, int ROUND> struct RoundLoop {
 template <int G, typename T>
 __global__ __launch_bounds__(64) void music_evd_group_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
                                                              double *__restrict__ coef_d, float2 *__restrict__ pn_out,
-                                                             int n_items, int N, int M)
+                                                             int n_items, int N, int M,
+                                                             const float2 *__restrict__ pilot, float2 *__restrict__ cal_out)
 {
     constexpr int IPW = kWave / G;                       // items per wave
     const int lane = threadIdx.x & (kWave - 1);
@@ -443,6 +444,33 @@ __global__ __launch_bounds__(64) void music_evd_group_kernel(const float2 *__res
     for (int j = 0; j < G; j++) {
         const T lj = lane_fetch<T>(lam, base + j);
         rank += ((lj < lam) || (lj == lam && j < r)) ? 1 : 0;
+    }
+    if (cal_out) {
+        // calibrate_lin_array (reference lib/calibrate_lin_array_impl.cc:98-134): U_S = eigenvector of the
+        // largest eigenvalue; W = diag(conj v) U_S U_S^H diag(v) is rank one, so its unit-eigenvalue
+        // eigenvector is conj(v) .* U_S (normalised).  Phase convention: element 0 real, non-negative.
+        const unsigned long long top_mask = __ballot((r < N) && (rank == N - 1));
+        const int imax = __builtin_ctzll(((top_mask >> base) & ((1ull << G) - 1ull)) | (1ull << G));   // column of the top eigenvector
+        T er = 0, ei = 0;
+#pragma unroll
+        for (int k = 0; k < G; k++) { er = (k == imax) ? vr[k] : er; ei = (k == imax) ? vi[k] : ei; }
+        const float2 pv = (r < N) ? pilot[r] : make_float2(1.f, 0.f);
+        // conj(v_r) * u_r
+        T wr = (T)pv.x * er + (T)pv.y * ei, wi = (T)pv.x * ei - (T)pv.y * er;
+        if (!(r < N)) { wr = 0; wi = 0; }
+        const T nrm2 = group_sum<G, T>(wr * wr + wi * wi, lane);
+        const T inv = Real<T>::rsqrt(nrm2 > (T)0 ? nrm2 : (T)1);
+        wr *= inv; wi *= inv;
+        const T w0r = lane_fetch<T>(wr, base), w0i = lane_fetch<T>(wi, base);
+        const T m0 = w0r * w0r + w0i * w0i;
+        if (m0 > (T)0) {                                   // rotate so that element 0 is real positive
+            const T im0 = Real<T>::rsqrt(m0);
+            const T cr = w0r * im0, ci = -w0i * im0;       // conj(w0)/|w0|
+            const T tr = wr * cr - wi * ci, ti = wr * ci + wi * cr;
+            wr = tr; wi = ti;
+        }
+        if (real_item && r < N) cal_out[(size_t)item * N + r] = make_float2((float)wr, (float)((r == 0) ? (T)0 : wi));
+        return;
     }
     const bool is_noise = (r < N) && (rank < N - M);
     const unsigned long long noise_mask = __ballot(is_noise);
@@ -500,12 +528,24 @@ __global__ __launch_bounds__(64) void music_evd_group_kernel(const float2 *__res
 
 template <int G, typename T>
 static void launch_evd_group(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
-                             hipStream_t st)
+                             hipStream_t st, const void *d_pilot = nullptr, void *d_cal = nullptr)
 {
     constexpr int IPW = kWave / G;
     dim3 block(64), grid((n_items + IPW - 1) / IPW);
     hipLaunchKernelGGL((music_evd_group_kernel<G, T>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,
-                       (double *)d_coef_d, (float2 *)d_pn, n_items, N, M);
+                       (double *)d_coef_d, (float2 *)d_pn, n_items, N, M, (const float2 *)d_pilot, (float2 *)d_cal);
+}
+
+// calibrate_lin_array: top eigenvector of each covariance item, de-rotated by the pilot steering vector
+int launch_calibrate(int N, int n_items, const void *d_R, const void *d_pilot, void *d_out, int bits, hipStream_t st)
+{
+    if (n_items <= 0) return DOA_OK;
+    const bool f32 = (bits == 32);
+    if (N > 8) { if (f32) launch_evd_group<16, float>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); else launch_evd_group<16, double>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); }
+    else if (N > 4) { if (f32) launch_evd_group<8, float>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); else launch_evd_group<8, double>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); }
+    else { if (f32) launch_evd_group<4, float>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); else launch_evd_group<4, double>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); }
+    DOA_HIP_TRY(hipGetLastError());
+    return DOA_OK;
 }
 
 template <int N> static void launch_evd_n(int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,

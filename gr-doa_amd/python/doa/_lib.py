@@ -90,6 +90,10 @@ SIGNATURES = {
     "doa_antenna_correction_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vpp, _vp]),
     "doa_autocorrelate_fuse_antenna_correction": (C.c_int, [_vp, _vp]),
     "doa_music_pipeline_fuse_antenna_correction": (C.c_int, [_vp, _vp]),
+    "doa_calibrate_lin_array_create": (_vp, [C.c_float, C.c_int, C.c_float]),
+    "doa_calibrate_lin_array_destroy": (None, [_vp]),
+    "doa_calibrate_lin_array_work": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "doa_calibrate_lin_array_work_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "doa_music_pipeline_create": (_vp, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]),
     "doa_music_pipeline_destroy": (None, [_vp]),
     "doa_music_pipeline_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp, _vp]),

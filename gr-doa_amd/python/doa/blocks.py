@@ -257,6 +257,33 @@ class rootMUSIC_linear_array(_Block):
                                                              C.c_void_p(int(d_out_ptr)), _stream_ptr(stream)))
 
 
+class calibrate_lin_array(_Block):
+    """doa.calibrate_lin_array(norm_spacing, num_ant_ele, pilot_angle) — gr::sync_block, vlen N^2
+    complex in, vlen N complex out (reference lib/calibrate_lin_array_impl.cc:46-75)."""
+
+    _destroy = staticmethod(lib.doa_calibrate_lin_array_destroy)
+
+    def __init__(self, norm_spacing, num_ant_ele, pilot_angle):
+        super().__init__()
+        self.norm_spacing, self.num_ant_ele, self.pilot_angle = float(norm_spacing), int(num_ant_ele), float(pilot_angle)
+        self._h = check_handle(lib.doa_calibrate_lin_array_create(self.norm_spacing, self.num_ant_ele, self.pilot_angle),
+                               "calibrate_lin_array")
+        self.in_sig = [(_C64, self.num_ant_ele ** 2)]
+        self.out_sig = [(_C64, self.num_ant_ele)]
+
+    def work(self, noutput_items, input_items, output_items) -> int:
+        n = int(noutput_items)
+        a = np.ascontiguousarray(input_items[0], dtype=_C64)
+        out = output_items[0]
+        assert a.size >= n * self.num_ant_ele ** 2
+        assert out.dtype == _C64 and out.flags.c_contiguous and out.size >= n * self.num_ant_ele
+        return check(lib.doa_calibrate_lin_array_work(self._h, n, _vp(a), _vp(out)))
+
+    def work_dev(self, noutput_items, d_in_ptr, d_out_ptr, stream=None) -> int:
+        return check(lib.doa_calibrate_lin_array_work_dev(self._h, int(noutput_items), C.c_void_p(int(d_in_ptr)),
+                                                          C.c_void_p(int(d_out_ptr)), _stream_ptr(stream)))
+
+
 class music_pipeline(_Block):
     """autocorrelate -> MUSIC_lin_array -> find_local_max(num_targets, pspectrum_len, 0, 180) on
     device-resident streams (the wiring of apps/run_MUSIC_lin_array_simulation.grc); the batch

@@ -8,12 +8,14 @@
 //   rootMUSIC_linear_array  gr::sync_block, io_signature(1, M, M floats), port 0 written
 //                           (…/rootMUSIC_linear_array_impl.cc:46-49,96)
 //   antenna_correction      gr::sync_block, N complex streams in/out (…/antenna_correction_impl.cc:47-52)
+//   calibrate_lin_array     gr::sync_block, vlen N^2 complex -> vlen N complex (…/calibrate_lin_array_impl.cc:46-51)
 // — and turn a failing ABI call into the behaviour a GNU Radio block has for it: constructors throw
 // std::runtime_error / std::invalid_argument (as antenna_correction_impl.cc:58-73 does), work()
 // returns WORK_DONE (-1) after logging, which stops the flowgraph.
 #include <doa/MUSIC_lin_array.h>
 #include <doa/antenna_correction.h>
 #include <doa/autocorrelate.h>
+#include <doa/calibrate_lin_array.h>
 #include <doa/find_local_max.h>
 #include <doa/rootMUSIC_linear_array.h>
 
@@ -163,8 +165,33 @@ public:
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+class calibrate_lin_array_hip : public calibrate_lin_array
+{
+    doa_calibrate_lin_array_t *d_h;
+
+public:
+    calibrate_lin_array_hip(float norm_spacing, int num_ant_ele, float pilot_angle)
+        : gr::sync_block("calibrate_lin_array", gr::io_signature::make(1, 1, num_ant_ele * num_ant_ele * sizeof(gr_complex)),
+                         gr::io_signature::make(1, 1, num_ant_ele * sizeof(gr_complex))),
+          d_h(doa_calibrate_lin_array_create(norm_spacing, num_ant_ele, pilot_angle))
+    {
+        if (!d_h) throw_create("doa::calibrate_lin_array");
+    }
+    ~calibrate_lin_array_hip() override { doa_calibrate_lin_array_destroy(d_h); }
+    int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) override
+    {
+        const int produced = doa_calibrate_lin_array_work(d_h, noutput_items, input_items[0], output_items[0]);
+        return produced < 0 ? work_failed("doa::calibrate_lin_array", produced) : produced;
+    }
+};
+
 }  // namespace
 
+calibrate_lin_array::sptr calibrate_lin_array::make(float norm_spacing, int num_ant_ele, float pilot_angle)
+{
+    return gnuradio::get_initial_sptr(new calibrate_lin_array_hip(norm_spacing, num_ant_ele, pilot_angle));
+}
 antenna_correction::sptr antenna_correction::make(int num_ant_ele, char *config_filename)
 {
     return gnuradio::get_initial_sptr(new antenna_correction_hip(num_ant_ele, config_filename));

@@ -196,6 +196,25 @@ DOA_HIP_API int doa_antenna_correction_work_dev(doa_antenna_correction_t *h, int
 DOA_HIP_API int doa_autocorrelate_fuse_antenna_correction(doa_autocorrelate_t *h, const float *gains_re_im);
 
 /* ---------------------------------------------------------------------------------------------
+ * calibrate_lin_array — gr::doa::calibrate_lin_array::make(norm_spacing, num_ant_ele, pilot_angle)
+ *   (include/doa/calibrate_lin_array.h, lib/calibrate_lin_array_impl.cc:36-134).  gr::sync_block:
+ *   input = column-major num_ant_ele^2 gr_complex covariance items measured with one pilot source at
+ *   pilot_angle degrees; output = num_ant_ele gr_complex per item, the estimated per-antenna complex
+ *   responses (unit-norm vector).  The reference's output carries an arbitrary unit-modulus factor
+ *   (LAPACK eigenvector phase); here element 0 is real and non-negative.  
+ * --------------------------------------------------------------------------------------------- */
+typedef struct doa_calibrate_lin_array doa_calibrate_lin_array_t;
+
+DOA_HIP_API doa_calibrate_lin_array_t *doa_calibrate_lin_array_create(float norm_spacing, int num_ant_ele,
+                                                                      float pilot_angle);
+DOA_HIP_API void doa_calibrate_lin_array_destroy(doa_calibrate_lin_array_t *h);
+DOA_HIP_API int doa_calibrate_lin_array_work(doa_calibrate_lin_array_t *h, int noutput_items,
+                                             const void *input_items0, void *output_items0);
+DOA_HIP_API int doa_calibrate_lin_array_work_dev(doa_calibrate_lin_array_t *h, int noutput_items,
+                                                 const void *d_input_items0, void *d_output_items0,
+                                                 void *hip_stream);
+
+/* ---------------------------------------------------------------------------------------------
  * music_pipeline — autocorrelate -> MUSIC_lin_array -> find_local_max(num_targets, pspectrum_len,
  *   0, 180) on device-resident streams, the batch entry point the benchmark drives
  *   (apps/run_MUSIC_lin_array_simulation.grc wiring).  All pointers are DEVICE pointers except

@@ -241,6 +241,51 @@ def music_lin_array(R_items: np.ndarray, norm_spacing: float, num_targets: int, 
 
 
 # --------------------------------------------------------------------------------------------
+# calibrate_lin_array  (lib/calibrate_lin_array_impl.cc)
+# --------------------------------------------------------------------------------------------
+def calibrate_pilot_vector(norm_spacing: float, num_ant_ele: int, pilot_angle: float, precision: str = "f32"):
+    """ctor: amv(v_temp, d_array_loc, pi*pilot_angle/180).  lib/calibrate_lin_array_impl.cc:57-70,83-89."""
+    loc = music_array_loc(norm_spacing, num_ant_ele)
+    theta = _F32(np.pi * float(_F32(pilot_angle)) / 180.0)
+    if precision == "f32":
+        k = _F32(-1.0 * 2 * np.pi * np.cos(float(theta)))
+        ph = (k * loc).astype(_F32)
+        return (np.cos(ph) + 1j * np.sin(ph)).astype(_C64)
+    d = float(_F32(norm_spacing))
+    loc64 = np.array([d * 0.5 * (num_ant_ele - 1 - 2 * nn) for nn in range(num_ant_ele)])
+    ph = -1.0 * 2 * np.pi * np.cos(float(theta)) * loc64
+    return np.cos(ph) + 1j * np.sin(ph)
+
+
+def calibrate_lin_array(R_items: np.ndarray, norm_spacing: float, num_ant_ele: int, pilot_angle: float,
+                        precision: str = "f32") -> np.ndarray:
+    """work() of doa::calibrate_lin_array, literally: two eig_sym per item.
+    lib/calibrate_lin_array_impl.cc:98-134.  Returns [n, N] complex; each row carries LAPACK's arbitrary
+    unit-modulus eigenvector phase (compare after `calibrate_normalise`)."""
+    N = num_ant_ele
+    v = calibrate_pilot_vector(norm_spacing, N, pilot_angle, precision)
+    cdt = _C64 if precision == "f32" else np.complex128
+    R_items = np.asarray(R_items)
+    out = np.empty((R_items.shape[0], N), dtype=cdt)
+    for item in range(R_items.shape[0]):
+        R = R_items[item].reshape(N, N, order="F")
+        _, V = _eig_sym(R, precision)
+        U_S = V[:, N - 1:N]                                       # :118
+        U_S_sq = (U_S @ U_S.conj().T).astype(cdt)                  # :119
+        W = (np.diag(np.conj(v)).astype(cdt) @ U_S_sq @ np.diag(v).astype(cdt)).astype(cdt)   # :122
+        _, WV = _eig_sym(W, precision)                             # :123
+        out[item] = WV[:, N - 1]                                   # :125
+    return out
+
+
+def calibrate_normalise(est: np.ndarray) -> np.ndarray:
+    """Remove the arbitrary unit-modulus factor: rotate each row so that element 0 is real >= 0."""
+    est = np.asarray(est)
+    ph = np.where(np.abs(est[:, :1]) > 0, np.conj(est[:, :1]) / np.maximum(np.abs(est[:, :1]), 1e-300), 1.0)
+    return est * ph
+
+
+# --------------------------------------------------------------------------------------------
 # find_local_max  (lib/find_local_max_impl.cc, lib/find_local_max_impl.h)
 # --------------------------------------------------------------------------------------------
 def find_local_max_x_axis(vector_len: int, x_min: float, x_max: float) -> np.ndarray:
