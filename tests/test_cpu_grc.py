@@ -30,6 +30,11 @@ EXPECT = {
         params={"num_inputs": None, "config_filename": "/tmp/antenna.cfg"},
         checks=[],
         sinks=[("complex", None, "$num_inputs")], sources=[("complex", None, "$num_inputs")]),
+    "doa_calibrate_lin_array": dict(
+        make="doa.calibrate_lin_array($norm_spacing, $num_ant_ele, $pilot_angle)",
+        params={"norm_spacing": "0.5", "num_ant_ele": "4", "pilot_angle": "45.0"},
+        checks=["$num_ant_ele > 1", "$norm_spacing <= 0.5"],
+        sinks=[("complex", "$num_ant_ele*$num_ant_ele", None)], sources=[("complex", "$num_ant_ele", None)]),
     "doa_rootMUSIC_linear_array": dict(
         make="doa.rootMUSIC_linear_array($norm_spacing, $num_targets, $inputs)",
         params={"norm_spacing": "0.5", "num_targets": "1", "inputs": "1"},
