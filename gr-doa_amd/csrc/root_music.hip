@@ -17,6 +17,8 @@
 // are NaN, and the host entry point returns DOA_ERR_NUMERIC.
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 namespace doa {
 
 template <int N, bool UNROLL>
@@ -139,11 +141,164 @@ __global__ __launch_bounds__(64) void root_music_kernel(const double *__restrict
     for (int j = 0; j < M; j++) o[j] = aoa[j];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Group-parallel Aberth-Ehrlich: GR lanes (the power of two >= 2N-2) share one item, one root per
+// lane.  Every lane evaluates p and p' at its own root by Horner (the 2N-1 coefficients are held
+// redundantly in registers, padded with zeros up to GR so the loop bounds are compile-time), reads
+// the other roots with cross-lane fetches for the Aberth correction, and all roots move
+// simultaneously.  The dependent chain per item is ~1/(2N-2) of the one-lane-per-item kernel's.
+// ---------------------------------------------------------------------------------------------
+template <int GR> __device__ __forceinline__ double group_max_d(double v, int lane)
+{
+#pragma unroll
+    for (int m = 1; m < GR; m <<= 1) v = fmax(v, __shfl(v, lane ^ m, kWave));
+    return v;
+}
+
+template <int GR>
+__global__ __launch_bounds__(64) void root_music_group_kernel(const double *__restrict__ coef, float *__restrict__ out,
+                                                              int *__restrict__ status, int n_items, int N, int M,
+                                                              double two_pi_d)
+{
+    constexpr int IPW = kWave / GR;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int k = lane % GR, base = lane - k;
+    int item = blockIdx.x * IPW + lane / GR;
+    const bool real_item = item < n_items;
+    if (!real_item) item = n_items - 1;
+    const int D = 2 * N - 2;
+    const bool is_root = k < D;
+    const double *co = coef + (size_t)item * (2 * N);
+    // polynomial c[m], m = 0..D: c[N-1-l] = u_l, c[N-1+l] = conj(u_l); zero above D
+    double cr[GR + 1], ci[GR + 1];
+#pragma unroll
+    for (int m = 0; m <= GR; m++) {
+        double vr = 0.0, vi = 0.0;
+        if (m <= D) {
+            const int l = (m <= N - 1) ? (N - 1 - m) : (m - (N - 1));
+            if (l == 0) vr = co[0];
+            else { vr = co[2 * l - 1]; vi = (m < N - 1) ? co[2 * l] : -co[2 * l]; }
+        }
+        cr[m] = vr; ci[m] = vi;
+    }
+    double zr, zi;
+    {
+        const double ang = 2.0 * M_PI * (k + 0.37) / D;
+        const double rad = 0.75 + 0.5 * ((k * 0.6180339887498949) - floor(k * 0.6180339887498949));
+        double sn, cs;
+        sincos(ang, &sn, &cs);
+        zr = is_root ? rad * cs : 1e6 * (k + 1);          // idle lanes park far away and never move
+        zi = is_root ? rad * sn : 0.0;
+    }
+    for (int it = 0; it < 160; it++) {
+        double pr = 0.0, pi = 0.0, dr = 0.0, di = 0.0;
+#pragma unroll
+        for (int m = GR; m >= 0; m--) {
+            const double ndr = dr * zr - di * zi + pr;
+            const double ndi = dr * zi + di * zr + pi;
+            dr = ndr; di = ndi;
+            const double npr = pr * zr - pi * zi + cr[m];
+            const double npi = pr * zi + pi * zr + ci[m];
+            pr = npr; pi = npi;
+        }
+        // (coefficients above degree D are zero, so starting the recurrence at GR changes nothing)
+        const double dn = dr * dr + di * di;
+        double wr = 1e-3, wi = 1e-3;
+        if (dn > 0.0) { wr = (pr * dr + pi * di) / dn; wi = (pi * dr - pr * di) / dn; }
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int j = 0; j < GR; j++) {
+            const double ojr = __shfl(zr, base + j, kWave), oji = __shfl(zi, base + j, kWave);
+            const double er = zr - ojr, ei = zi - oji;
+            const double en = er * er + ei * ei;
+            if (j != k && j < D && en > 0.0) { sr += er / en; si -= ei / en; }
+        }
+        const double qr = 1.0 - (wr * sr - wi * si), qi = -(wr * si + wi * sr);
+        const double qn = qr * qr + qi * qi;
+        double er = wr, ei = wi;
+        if (qn > 0.0) { er = (wr * qr + wi * qi) / qn; ei = (wi * qr - wr * qi) / qn; }
+        double rel = 0.0;
+        if (is_root) {
+            zr -= er; zi -= ei;
+            rel = (er * er + ei * ei) / (1.0 + zr * zr + zi * zi);
+        }
+        const double worst = group_max_d<GR>(rel, lane);
+        if (!__any(worst >= 1e-29)) break;          // every group of the wave has converged
+    }
+    // dist = 1 - |z|; keep dist > 0; the M smallest, one at a time (:122-141)
+    double dist = is_root ? 1.0 - sqrt(zr * zr + zi * zi) : -1.0;
+    if (!(dist > 0.0)) dist = -1.0;
+    const unsigned long long inside_mask = __ballot(dist > 0.0);
+    const int n_inside = __popcll((inside_mask >> base) & ((GR == 64) ? ~0ull : ((1ull << GR) - 1ull)));
+    float my_aoa = 0.f;
+    for (int j = 0; j < M; j++) {
+        // group arg-min of dist over the remaining interior roots (ties -> lowest lane)
+        double bd = (dist > 0.0) ? dist : 1e300;
+        int bk = (dist > 0.0) ? k : GR;
+#pragma unroll
+        for (int m = 1; m < GR; m <<= 1) {
+            const double od = __shfl(bd, lane ^ m, kWave);
+            const int ok = __shfl(bk, lane ^ m, kWave);
+            if (od < bd || (od == bd && ok < bk)) { bd = od; bk = ok; }
+        }
+        double ang = 0.0;                                   // exhausted: arg(inf + 0i) = 0 -> 90 degrees
+        if (bk < GR) {
+            const double br = __shfl(zr, base + bk, kWave), bi = __shfl(zi, base + bk, kWave);
+            ang = atan2(bi, br);
+            if (k == bk) dist = -1.0;
+        }
+        const float a = (float)(180.0 * acos(ang / two_pi_d) / M_PI);
+        if (k == j) my_aoa = a;
+    }
+    // ascending sort of the M picks held by lanes 0..M-1 (NaN sorts last)
+    const float key = (my_aoa != my_aoa) ? INFINITY : my_aoa;
+    int rank = 0;
+    for (int j = 0; j < M; j++) {
+        const float kj = __shfl(key, base + j, kWave);
+        rank += (kj < key || (kj == key && j < k)) ? 1 : 0;
+    }
+    if (real_item) {
+        float *o = out + (size_t)item * M;
+        if (n_inside == 0) {
+            if (k < M) o[k] = __builtin_nanf("");
+            if (k == 0 && status) status[item] = 1;
+        } else {
+            if (k < M) o[rank] = my_aoa;
+            if (k == 0 && status) status[item] = 0;
+        }
+    }
+}
+
+template <int GR>
+static void launch_root_group(int N, int M, int n_items, const void *d_coef, void *d_out, void *d_status, double two_pi_d,
+                              hipStream_t st)
+{
+    constexpr int IPW = kWave / GR;
+    dim3 block(64), grid((n_items + IPW - 1) / IPW);
+    hipLaunchKernelGGL(root_music_group_kernel<GR>, grid, block, 0, st, (const double *)d_coef, (float *)d_out,
+                       (int *)d_status, n_items, N, M, two_pi_d);
+}
+
 int launch_root_music(int N, int M, float norm_spacing, int n_items, const void *d_coef, void *d_out, void *d_status,
                       hipStream_t st)
 {
     if (n_items <= 0) return DOA_OK;
     const double two_pi_d = 2 * M_PI * (double)norm_spacing;   // 2*datum::pi*d_norm_spacing, float promoted (:135)
+    static const int serial = [] { const char *e = getenv("DOA_ROOT_SERIAL"); return e ? atoi(e) : 0; }();
+    if (N < 2 || N > DOA_MAX_ANT_ELE) {
+        set_error("rootMUSIC: num_ant_ele=%d outside the built range 2..%d", N, DOA_MAX_ANT_ELE);
+        return DOA_ERR_UNSUPPORTED;
+    }
+    if (!serial) {
+        const int D = 2 * N - 2;
+        if (D <= 2) launch_root_group<2>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
+        else if (D <= 4) launch_root_group<4>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
+        else if (D <= 8) launch_root_group<8>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
+        else if (D <= 16) launch_root_group<16>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
+        else launch_root_group<32>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
+        DOA_HIP_TRY(hipGetLastError());
+        return DOA_OK;
+    }
     dim3 block(64), grid((n_items + 63) / 64);
     switch (N) {
 #define DOA_ROOT_CASE(n)                                                                                   \
@@ -151,12 +306,10 @@ int launch_root_music(int N, int M, float norm_spacing, int n_items, const void 
         hipLaunchKernelGGL(root_music_kernel<n>, grid, block, 0, st, (const double *)d_coef, (float *)d_out, \
                            (int *)d_status, n_items, M, two_pi_d);                                         \
         break;
-        DOA_ROOT_CASE(2) DOA_ROOT_CASE(3) DOA_ROOT_CASE(4) DOA_ROOT_CASE(5) DOA_ROOT_CASE(6) DOA_ROOT_CASE(7)
-        DOA_ROOT_CASE(8) DOA_ROOT_CASE(9) DOA_ROOT_CASE(10) DOA_ROOT_CASE(11) DOA_ROOT_CASE(12) DOA_ROOT_CASE(13)
-        DOA_ROOT_CASE(14) DOA_ROOT_CASE(15) DOA_ROOT_CASE(16)
+        DOA_ROOT_CASE(2) DOA_ROOT_CASE(3) DOA_ROOT_CASE(4)
 #undef DOA_ROOT_CASE
     default:
-        set_error("rootMUSIC: num_ant_ele=%d outside the built range 2..%d", N, DOA_MAX_ANT_ELE);
+        set_error("rootMUSIC: the one-lane-per-item kernel is only built for num_ant_ele <= 4");
         return DOA_ERR_UNSUPPORTED;
     }
     DOA_HIP_TRY(hipGetLastError());
