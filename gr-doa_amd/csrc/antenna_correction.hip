@@ -49,9 +49,9 @@ template <bool VEC2> __global__ __launch_bounds__(256) void antenna_correction_k
     if constexpr (VEC2) {
         const long long npair = a.n >> 1;
         for (; i < npair; i += stride) {
-            const float4 v = reinterpret_cast<const float4 *>(in)[i];
+            const float4 v = load_f4<true>(reinterpret_cast<const float4 *>(in) + i);
             const float2 y0 = cmul_nofma(g, make_float2(v.x, v.y)), y1 = cmul_nofma(g, make_float2(v.z, v.w));
-            reinterpret_cast<float4 *>(out)[i] = make_float4(y0.x, y0.y, y1.x, y1.y);
+            store_f4<true>(reinterpret_cast<float4 *>(out) + i, make_float4(y0.x, y0.y, y1.x, y1.y));
         }
         if ((a.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[a.n - 1] = cmul_nofma(g, in[a.n - 1]);
     } else {

@@ -55,7 +55,7 @@ template <int TN> __device__ __forceinline__ void tri_accumulate(TriAcc<TN> &acc
 
 // One wave per snapshot, N = TN <= 8, Hermitian symmetry exploited.
 // VEC2: all streams 16-B aligned at every window start (base % 16 == 0, S even) -> float4 loads.
-template <int TN, bool VEC2, int UN>
+template <int TN, bool VEC2, int UN, bool NT = false>
 __global__ __launch_bounds__(256) void cov_wave_kernel(CovArgs g)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void cov_wave_kernel(CovArgs g)
             for (int u = 0; u < UN; u++)
 #pragma unroll
                 for (int a = 0; a < TN; a++)
-                    v[u][a] = *reinterpret_cast<const float4 *>(g.in[a] + base + 2 * (size_t)(p + u * kWave));
+                    v[u][a] = load_f4<NT>(reinterpret_cast<const float4 *>(g.in[a] + base + 2 * (size_t)(p + u * kWave)));
 #pragma unroll
             for (int u = 0; u < UN; u++) {
                 float2 x0[TN], x1[TN];
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void cov_wave_kernel(CovArgs g)
         for (; p < npair; p += kWave) {
             float4 v[TN];
 #pragma unroll
-            for (int a = 0; a < TN; a++) v[a] = *reinterpret_cast<const float4 *>(g.in[a] + base + 2 * (size_t)p);
+            for (int a = 0; a < TN; a++) v[a] = load_f4<NT>(reinterpret_cast<const float4 *>(g.in[a] + base + 2 * (size_t)p));
             float2 x0[TN], x1[TN];
 #pragma unroll
             for (int a = 0; a < TN; a++) { x0[a] = make_float2(v[a].x, v[a].y); x1[a] = make_float2(v[a].z, v[a].w); }
@@ -197,6 +197,8 @@ template <bool VEC2> __global__ __launch_bounds__(256) void cov_mfma_kernel(CovA
 #pragma unroll
             for (int u = 0; u < UN; u++) {
                 if constexpr (VEC2) {
+                    // default cache policy on purpose: the two 16-byte halves of a lane's 32 bytes share
+                    // 128-byte lines with the neighbouring lanes' and want to meet in L1 (non-temporal: -50 %)
                     const float4 v0 = *reinterpret_cast<const float4 *>(p + t + 16 * u);
                     const float4 v1 = *reinterpret_cast<const float4 *>(p + t + 16 * u + 2);
                     x[u][0] = make_float2(v0.x, v0.y); x[u][1] = make_float2(v0.z, v0.w);
@@ -294,7 +296,9 @@ template <int TN> static void launch_wave(const CovArgs &g, bool vec2, hipStream
         default: break;
         }
     }
-    hipLaunchKernelGGL((cov_wave_kernel<TN, true, UN_DEF>), grid, block, 0, st, g);
+    static const int nt = [] { const char *e = getenv("DOA_COV_NT"); return e ? atoi(e) : 1; }();   // read-once stream: non-temporal loads, +19 % on MI355X
+    if (nt) hipLaunchKernelGGL((cov_wave_kernel<TN, true, UN_DEF, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((cov_wave_kernel<TN, true, UN_DEF, false>), grid, block, 0, st, g);
 }
 
 // Launches K1 on `st`.  d_in: N device pointers.  Returns DOA_OK / error.

@@ -52,6 +52,27 @@ int internal_precision_bits();  // 32 or 64 (doa_set_internal_precision)
 // ---- device-side wave primitives (wave = 64 lanes on gfx950) -----------------------------------
 constexpr int kWave = 64;
 
+// streamed-once data: non-temporal 16-byte accesses (read-once input samples, write-once spectra)
+typedef float doa_f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 load_f4(const float4 *p)
+{
+    if constexpr (NT) {
+        const doa_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const doa_f32x4 *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
+template <bool NT> __device__ __forceinline__ void store_f4(float4 *p, float4 v)
+{
+    if constexpr (NT) {
+        doa_f32x4 t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<doa_f32x4 *>(p));
+    } else {
+        *p = v;
+    }
+}
+
 // Cross-lane moves without LDS: DPP row operations (gfx9 encodings) + one v_readlane.
 //   quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_ror:4 = 0x124, row_ror:8 = 0x128,
 //   row_bcast:15 = 0x142 (lane 15 of each row -> the next row), row_bcast:31 = 0x143.

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void find_local_max_kernel(const float *__rest
     for (int j = 0; j < CH; j++) {
         const int p0 = 256 * j + 4 * lane;
         if (p0 < L) {   // L % 4 == 0: a float4 is entirely inside or outside
-            const float4 t = *reinterpret_cast<const float4 *>(v_in + p0);
+            const float4 t = load_f4<true>(reinterpret_cast<const float4 *>(v_in + p0));
             v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
         } else {
             v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;

@@ -627,7 +627,7 @@ __device__ __forceinline__ float db_from_ratio(float out, float mx, float inv_mx
 // z table (4*CH angles per lane) is loaded once per wave and stays in registers.  With PEAK the
 // find_local_max step (K5) runs on the dB values while they are still in registers, so the spectrum
 // is written once and never read back.
-template <int N, int CH, typename T, bool HAS_Q, bool PEAK>
+template <int N, int CH, typename T, bool HAS_Q, bool PEAK, bool NT = false>
 __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                          float *__restrict__ spec, float *__restrict__ qout, int P,
                                                          int n_items, const float *__restrict__ xaxis,
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
             const int i0 = 4 * lane + 256 * j;
 #pragma unroll
             for (int e = 0; e < 4; e++) out[j][e] = db_from_ratio(out[j][e], mx, inv_mx);   // now dB
-            if (i0 < P) *reinterpret_cast<float4 *>(row + i0) = make_float4(out[j][0], out[j][1], out[j][2], out[j][3]);
+            if (i0 < P) store_f4<NT>(reinterpret_cast<float4 *>(row + i0), make_float4(out[j][0], out[j][1], out[j][2], out[j][3]));
         }
         if constexpr (PEAK) peak_pick<CH>(out, lane, P, M, xaxis, pk_val + (size_t)item * M, pk_loc + (size_t)item * M);
     }
@@ -733,9 +733,11 @@ static void launch_scan_fast(dim3 grid, dim3 block, hipStream_t st, const T *co,
     if (q)
         hipLaunchKernelGGL((music_scan_kernel<N, CH, T, true, false>), grid, block, 0, st, co, z, sp, q, P, n_items,
                            nullptr, nullptr, nullptr, 0);
-    else if (pk.val)
-        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, true>), grid, block, 0, st, co, z, sp, q, P, n_items,
-                           pk.xaxis, pk.val, pk.loc, pk.M);
+    else if (pk.val) {
+        static const int nt = [] { const char *e = getenv("DOA_SCAN_NT"); return e ? atoi(e) : 1; }();   // write-once spectrum: non-temporal stores
+        if (nt) hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, true, true>), grid, block, 0, st, co, z, sp, q, P, n_items, pk.xaxis, pk.val, pk.loc, pk.M);
+        else hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, true, false>), grid, block, 0, st, co, z, sp, q, P, n_items, pk.xaxis, pk.val, pk.loc, pk.M);
+    }
     else
         hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, false>), grid, block, 0, st, co, z, sp, q, P, n_items,
                            nullptr, nullptr, nullptr, 0);
