@@ -631,8 +631,12 @@ template <int N, int CH, typename T, bool HAS_Q, bool PEAK, bool NT = false>
 __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                          float *__restrict__ spec, float *__restrict__ qout, int P,
                                                          int n_items, const float *__restrict__ xaxis,
-                                                         float *__restrict__ pk_val, float *__restrict__ pk_loc, int M)
+                                                         float *__restrict__ pk_val, float *__restrict__ pk_loc, int M,
+                                                         int n_ant)
 {
+    // N is the compiled polynomial size (>= n_ant, the array's element count): records are 2*n_ant
+    // values long and the missing high-order coefficients are zero, which leaves Q unchanged
+    const int rec = 2 * n_ant;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
     const int n_waves = gridDim.x * (blockDim.x / kWave);
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
     T c[2 * N], c_next[2 * N];
     if (wave < n_items) {
 #pragma unroll
-        for (int k = 0; k < 2 * N; k++) c_next[k] = coef[(size_t)wave * (2 * N) + k];
+        for (int k = 0; k < 2 * N; k++) c_next[k] = (k < rec - 1) ? coef[(size_t)wave * rec + k] : (T)0;
     }
     for (int item = wave; item < n_items; item += n_waves) {
 #pragma unroll
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
         const int nxt = item + n_waves;
         if (nxt < n_items) {
 #pragma unroll
-            for (int k = 0; k < 2 * N; k++) c_next[k] = coef[(size_t)nxt * (2 * N) + k];
+            for (int k = 0; k < 2 * N; k++) c_next[k] = (k < rec - 1) ? coef[(size_t)nxt * rec + k] : (T)0;
         }
         float out[CH][4];
         float mx = -INFINITY;
@@ -695,16 +699,17 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
 template <int N, typename T>
 __global__ __launch_bounds__(256) void music_scan_generic_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                                  float *__restrict__ spec, float *__restrict__ qout, int P,
-                                                                 int n_items)
+                                                                 int n_items, int n_ant)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
     const int n_waves = gridDim.x * (blockDim.x / kWave);
+    const int rec = 2 * n_ant;
     for (int item = wave; item < n_items; item += n_waves) {
-        const T *co = coef + (size_t)item * (2 * N);
+        const T *co = coef + (size_t)item * rec;
         T c[2 * N];
 #pragma unroll
-        for (int k = 0; k < 2 * N; k++) c[k] = co[k];
+        for (int k = 0; k < 2 * N; k++) c[k] = (k < rec - 1) ? co[k] : (T)0;
         float mx = -INFINITY;
         for (int i = lane; i < P; i += kWave) {
             const float q = (float)null_spectrum<N, T>(c, ztab[2 * i], ztab[2 * i + 1]);
@@ -728,48 +733,48 @@ struct ScanPeakArgs {           // optional fused K5
 
 template <int N, int CH, typename T>
 static void launch_scan_fast(dim3 grid, dim3 block, hipStream_t st, const T *co, const T *z, float *sp, float *q, int P,
-                             int n_items, const ScanPeakArgs &pk)
+                             int n_items, const ScanPeakArgs &pk, int n_ant)
 {
+    // three variants: diagnostics (Q out), plain, fused with the peak pick; spectra are write-once ->
+    // non-temporal stores in the two production variants
     if (q)
-        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, true, false>), grid, block, 0, st, co, z, sp, q, P, n_items,
-                           nullptr, nullptr, nullptr, 0);
-    else if (pk.val) {
-        static const int nt = [] { const char *e = getenv("DOA_SCAN_NT"); return e ? atoi(e) : 1; }();   // write-once spectrum: non-temporal stores
-        if (nt) hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, true, true>), grid, block, 0, st, co, z, sp, q, P, n_items, pk.xaxis, pk.val, pk.loc, pk.M);
-        else hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, true, false>), grid, block, 0, st, co, z, sp, q, P, n_items, pk.xaxis, pk.val, pk.loc, pk.M);
-    }
+        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, true, false, false>), grid, block, 0, st, co, z, sp, q, P, n_items,
+                           nullptr, nullptr, nullptr, 0, n_ant);
+    else if (pk.val)
+        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, true, true>), grid, block, 0, st, co, z, sp, q, P, n_items,
+                           pk.xaxis, pk.val, pk.loc, pk.M, n_ant);
     else
-        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, false>), grid, block, 0, st, co, z, sp, q, P, n_items,
-                           nullptr, nullptr, nullptr, 0);
+        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, false, true>), grid, block, 0, st, co, z, sp, q, P, n_items,
+                           nullptr, nullptr, nullptr, 0, n_ant);
 }
 
 // returns true when the fused peak pick ran (fast path only)
 template <int N, typename T>
 static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_spec, void *d_q, const ScanPeakArgs &pk,
-                           hipStream_t st)
+                           int n_ant, hipStream_t st)
 {
     float *sp = (float *)d_spec, *q = (float *)d_q;
     const int waves_per_block = 4;
     const bool aligned = (P % 4 == 0) && (reinterpret_cast<uintptr_t>(d_spec) % 16 == 0);
-    // enough waves to fill the chip several times over, few enough that each wave amortises its
-    // z-table load over several items
+    // two items per wave at the benchmark batch: the z table is loaded once per wave and the next
+    // item's coefficient record is prefetched behind the current item's arithmetic
     int blocks = (n_items + waves_per_block - 1) / waves_per_block;
     static const int wpc = [] { const char *e = getenv("DOA_SCAN_WAVES_PER_CU"); return e ? atoi(e) : 8; }();
-    const int max_blocks = 256 * wpc / waves_per_block;   // default 8 waves per CU: 2 items per wave at batch 4096
+    const int max_blocks = 256 * wpc / waves_per_block;
     if (blocks > max_blocks) blocks = max_blocks;
     dim3 grid(blocks), block(waves_per_block * kWave);
     const int max_ch = (sizeof(T) == 4) ? 16 : 4;        // double z table: 4 chunks fit the register file
     if (aligned && P <= 256 * max_ch) {
-        if (P <= 256) launch_scan_fast<N, 1, T>(grid, block, st, co, z, sp, q, P, n_items, pk);
-        else if (P <= 512) launch_scan_fast<N, 2, T>(grid, block, st, co, z, sp, q, P, n_items, pk);
-        else if (P <= 1024) launch_scan_fast<N, 4, T>(grid, block, st, co, z, sp, q, P, n_items, pk);
+        if (P <= 256) launch_scan_fast<N, 1, T>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
+        else if (P <= 512) launch_scan_fast<N, 2, T>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
+        else if (P <= 1024) launch_scan_fast<N, 4, T>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
         else if constexpr (sizeof(T) == 4) {
-            if (P <= 2048) launch_scan_fast<N, 8, T>(grid, block, st, co, z, sp, q, P, n_items, pk);
-            else launch_scan_fast<N, 16, T>(grid, block, st, co, z, sp, q, P, n_items, pk);
+            if (P <= 2048) launch_scan_fast<N, 8, T>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
+            else launch_scan_fast<N, 16, T>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
         }
         return pk.val != nullptr && q == nullptr;
     }
-    hipLaunchKernelGGL((music_scan_generic_kernel<N, T>), grid, block, 0, st, co, z, sp, q, P, n_items);
+    hipLaunchKernelGGL((music_scan_generic_kernel<N, T>), grid, block, 0, st, co, z, sp, q, P, n_items, n_ant);
     return false;
 }
 
@@ -777,8 +782,8 @@ template <int N> static bool launch_scan_n(const MusicTables &t, int bits, int n
                                            void *d_q, const ScanPeakArgs &pk, hipStream_t st)
 {
     if (bits == 32)
-        return launch_scan_nt<N, float>((const float *)d_coef, t.d_z.as<float>(), t.P, n_items, d_spec, d_q, pk, st);
-    return launch_scan_nt<N, double>((const double *)d_coef, t.d_zd.as<double>(), t.P, n_items, d_spec, d_q, pk, st);
+        return launch_scan_nt<N, float>((const float *)d_coef, t.d_z.as<float>(), t.P, n_items, d_spec, d_q, pk, t.N, st);
+    return launch_scan_nt<N, double>((const double *)d_coef, t.d_zd.as<double>(), t.P, n_items, d_spec, d_q, pk, t.N, st);
 }
 
 int launch_music_scan(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec, void *d_q,
@@ -791,16 +796,20 @@ int launch_music_scan(const MusicTables &t, int bits, int n_items, const void *d
         pk.xaxis = peaks->d_x.as<float>(); pk.val = (float *)d_max; pk.loc = (float *)d_argmax; pk.M = peaks->M;
     }
     bool done = false;
-    switch (t.N) {
-#define DOA_SCAN_CASE(n) case n: done = launch_scan_n<n>(t, bits, n_items, d_coef, d_spec, d_q, pk, st); break;
-        DOA_SCAN_CASE(2) DOA_SCAN_CASE(3) DOA_SCAN_CASE(4) DOA_SCAN_CASE(5) DOA_SCAN_CASE(6) DOA_SCAN_CASE(7)
-        DOA_SCAN_CASE(8) DOA_SCAN_CASE(9) DOA_SCAN_CASE(10) DOA_SCAN_CASE(11) DOA_SCAN_CASE(12) DOA_SCAN_CASE(13)
-        DOA_SCAN_CASE(14) DOA_SCAN_CASE(15) DOA_SCAN_CASE(16)
-#undef DOA_SCAN_CASE
-    default:
-        set_error("MUSIC: num_ant_ele=%d outside the built range 2..%d", t.N, DOA_MAX_ANT_ELE);
+    // compiled polynomial sizes: 2, 3, 4, 6, 8, 12, 16 (an array of n elements uses the next size up
+    // with zero high-order coefficients)
+    const int n = t.N;
+    if (n < 2 || n > DOA_MAX_ANT_ELE) {
+        set_error("MUSIC: num_ant_ele=%d outside the built range 2..%d", n, DOA_MAX_ANT_ELE);
         return DOA_ERR_UNSUPPORTED;
     }
+    if (n == 2) done = launch_scan_n<2>(t, bits, n_items, d_coef, d_spec, d_q, pk, st);
+    else if (n == 3) done = launch_scan_n<3>(t, bits, n_items, d_coef, d_spec, d_q, pk, st);
+    else if (n == 4) done = launch_scan_n<4>(t, bits, n_items, d_coef, d_spec, d_q, pk, st);
+    else if (n <= 6) done = launch_scan_n<6>(t, bits, n_items, d_coef, d_spec, d_q, pk, st);
+    else if (n <= 8) done = launch_scan_n<8>(t, bits, n_items, d_coef, d_spec, d_q, pk, st);
+    else if (n <= 12) done = launch_scan_n<12>(t, bits, n_items, d_coef, d_spec, d_q, pk, st);
+    else done = launch_scan_n<16>(t, bits, n_items, d_coef, d_spec, d_q, pk, st);
     if (peaks_done) *peaks_done = done;
     DOA_HIP_TRY(hipGetLastError());
     return DOA_OK;
