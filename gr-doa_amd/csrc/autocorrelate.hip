@@ -257,13 +257,6 @@ __global__ void cov_fb_kernel(float2 *out, int nn, long long n_items, float fb_h
     if (e2 != e) p[e2] = nv;
 }
 
-// loads kept in flight per wave = UN*TN 16-byte loads; tuned on MI355X
-static int cov_unroll_override()
-{
-    static int v = [] { const char *e = getenv("DOA_COV_UN"); return e ? atoi(e) : 0; }();
-    return v;
-}
-
 // Waves per CU one launch may occupy (0 = one wave per snapshot, no cap).  8 is enough to saturate
 // HBM (8 x 16 KiB in flight per CU) and leaves half of every CU's wave slots to the EVD / scan
 // kernels of neighbouring batches running on other streams: measured +8 % pipeline throughput at
@@ -283,22 +276,16 @@ template <int TN> static void launch_wave(const CovArgs &g, bool vec2, hipStream
         if (blocks > cap) blocks = cap;
     }
     dim3 grid(blocks), block(waves_per_block * kWave);
-    constexpr int UN_DEF = (TN <= 4) ? 4 : ((TN <= 6) ? 2 : 1);
+    // UN*TN 16-byte loads in flight per wave (UN = 1, 2, 8 measured within 3 % of UN = 4 at N = 4)
+    constexpr int UN = (TN <= 4) ? 4 : ((TN <= 6) ? 2 : 1);
     if (!vec2) {
-        hipLaunchKernelGGL((cov_wave_kernel<TN, false, 1>), grid, block, 0, st, g);
+        hipLaunchKernelGGL((cov_wave_kernel<TN, false, 1, false>), grid, block, 0, st, g);
         return;
     }
-    if constexpr (TN == 4) {   // the benchmark shape: variants kept for A/B runs
-        switch (cov_unroll_override()) {
-        case 1: hipLaunchKernelGGL((cov_wave_kernel<TN, true, 1>), grid, block, 0, st, g); return;
-        case 2: hipLaunchKernelGGL((cov_wave_kernel<TN, true, 2>), grid, block, 0, st, g); return;
-        case 8: hipLaunchKernelGGL((cov_wave_kernel<TN, true, 8>), grid, block, 0, st, g); return;
-        default: break;
-        }
-    }
-    static const int nt = [] { const char *e = getenv("DOA_COV_NT"); return e ? atoi(e) : 1; }();   // read-once stream: non-temporal loads, +19 % on MI355X
-    if (nt) hipLaunchKernelGGL((cov_wave_kernel<TN, true, UN_DEF, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((cov_wave_kernel<TN, true, UN_DEF, false>), grid, block, 0, st, g);
+    // read-once stream: non-temporal loads (+19 % on MI355X); DOA_COV_NT=0 restores the default policy
+    static const int nt = [] { const char *e = getenv("DOA_COV_NT"); return e ? atoi(e) : 1; }();
+    if (nt) hipLaunchKernelGGL((cov_wave_kernel<TN, true, UN, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((cov_wave_kernel<TN, true, UN, false>), grid, block, 0, st, g);
 }
 
 // Launches K1 on `st`.  d_in: N device pointers.  Returns DOA_OK / error.
