@@ -52,6 +52,18 @@ int internal_precision_bits();  // 32 or 64 (doa_set_internal_precision)
 // ---- device-side wave primitives (wave = 64 lanes on gfx950) -----------------------------------
 constexpr int kWave = 64;
 
+__device__ __forceinline__ int wave_allreduce_min_int(int v)
+{
+    auto step = [](int x, int y) { return x < y ? x : y; };
+    v = step(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // streamed-once data: non-temporal 16-byte accesses (read-once input samples, write-once spectra)
 typedef float doa_f32x4 __attribute__((ext_vector_type(4)));
 template <bool NT> __device__ __forceinline__ float4 load_f4(const float4 *p)

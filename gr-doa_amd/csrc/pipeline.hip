@@ -110,12 +110,12 @@ int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput_items, cons
     if (noutput_items == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     // DOA_PIPE_SKIP=cov,evd,scan: profiling aid that drops stages (outputs are then meaningless)
-    static const unsigned skip = [] {
-        const char *e = getenv("DOA_PIPE_SKIP");
-        unsigned m = 0;
-        if (e) { if (strstr(e, "cov")) m |= 1; if (strstr(e, "evd")) m |= 2; if (strstr(e, "scan")) m |= 4; }
-        return m;
-    }();
+    unsigned skip = 0;      // read per call so that a profiling script can populate the intermediates first
+    if (const char *e = getenv("DOA_PIPE_SKIP")) {
+        if (strstr(e, "cov")) skip |= 1;
+        if (strstr(e, "evd")) skip |= 2;
+        if (strstr(e, "scan")) skip |= 4;
+    }
     void *cov = d_cov_out ? d_cov_out : h->d_cov.p;
     void *spec = d_spectrum_out ? d_spectrum_out : h->d_spec.p;
     int rc = DOA_OK;
