@@ -151,6 +151,7 @@ int doa_antenna_correction_work_dev(doa_antenna_correction_t *h, int noutput_ite
         doa::set_error("antenna_correction_work_dev: bad arguments");
         return DOA_ERR_INVALID_ARG;
     }
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     int rc = doa::launch_antenna_correction(h->N, h->gains, noutput_items, d_input_items, d_output_items,
                                             static_cast<hipStream_t>(hip_stream));
     return rc == DOA_OK ? noutput_items : rc;
@@ -165,6 +166,7 @@ int doa_antenna_correction_work(doa_antenna_correction_t *h, int noutput_items, 
         return DOA_ERR_INVALID_ARG;
     }
     if (noutput_items == 0) return 0;
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     const size_t n = (size_t)noutput_items, n_al = (n + 1) & ~(size_t)1;
     int rc = h->d_in.reserve(n_al * h->N * sizeof(float2));
     if (rc == DOA_OK) rc = h->d_out.reserve(n_al * h->N * sizeof(float2));

@@ -428,6 +428,7 @@ int doa_autocorrelate_work_dev(doa_autocorrelate_t *h, int noutput_items, const 
         doa::set_error("autocorrelate_work_dev: bad arguments");
         return DOA_ERR_INVALID_ARG;
     }
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     int rc = doa::launch_autocorrelate(h->inputs, h->snapshot, h->overlap, h->avg, noutput_items, d_input_items,
                                        d_output_items0, static_cast<hipStream_t>(hip_stream),
                                        h->has_gain ? h->d_gain.p : nullptr);
@@ -443,6 +444,7 @@ int doa_autocorrelate_work(doa_autocorrelate_t *h, int noutput_items, const void
         return DOA_ERR_INVALID_ARG;
     }
     if (noutput_items == 0) return 0;
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     const int N = h->inputs;
     const size_t span = (size_t)doa_autocorrelate_input_span(h, noutput_items);
     const size_t span_al = (span + 1) & ~(size_t)1;  // keep every stream 16-B aligned on the device

@@ -73,6 +73,7 @@ int doa_calibrate_lin_array_work_dev(doa_calibrate_lin_array_t *h, int noutput_i
         doa::set_error("calibrate_lin_array_work_dev: bad arguments");
         return DOA_ERR_INVALID_ARG;
     }
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     int rc = doa::launch_calibrate(h->N, noutput_items, d_input_items0, h->d_pilot.p, d_output_items0, h->bits,
                                    static_cast<hipStream_t>(hip_stream));
     return rc == DOA_OK ? noutput_items : rc;

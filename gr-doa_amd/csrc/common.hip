@@ -33,6 +33,14 @@ int ensure_device(int *device_out)
     return DOA_OK;
 }
 
+int bind_device(int device)
+{
+    int cur = -1;
+    DOA_HIP_TRY(hipGetDevice(&cur));
+    if (cur != device) DOA_HIP_TRY(hipSetDevice(device));
+    return DOA_OK;
+}
+
 int DevBuf::reserve(size_t bytes)
 {
     if (bytes <= cap) return DOA_OK;

@@ -30,6 +30,8 @@ void clear_error();
 
 // Binds the calling thread to a usable HIP device (the current one); DOA_ERR_NO_DEVICE if none.
 int ensure_device(int *device_out);
+// Makes `device` (the one the handle was created on) current for the calling thread if it is not.
+int bind_device(int device);
 
 // ---- grow-only device / pinned-host buffers ----------------------------------------------------
 struct DevBuf {

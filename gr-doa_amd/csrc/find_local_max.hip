@@ -220,6 +220,7 @@ int doa_find_local_max_work_dev(doa_find_local_max_t *h, int noutput_items, cons
         return DOA_ERR_INVALID_ARG;
     }
     if (noutput_items == 0) return 0;
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     int rc;
     if (doa::find_local_max_fast_ok(h->tab.L, d_input_items0)) {
@@ -242,6 +243,7 @@ int doa_find_local_max_work(doa_find_local_max_t *h, int noutput_items, const vo
         return DOA_ERR_INVALID_ARG;
     }
     if (noutput_items == 0) return 0;
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     const size_t in_bytes = (size_t)noutput_items * h->tab.L * sizeof(float);
     const size_t out_bytes = (size_t)noutput_items * h->tab.M * sizeof(float);
     int rc = h->d_in.reserve(in_bytes);

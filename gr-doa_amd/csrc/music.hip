@@ -1056,6 +1056,7 @@ int doa_MUSIC_lin_array_work_dev(doa_MUSIC_lin_array_t *h, int noutput_items, co
         return DOA_ERR_INVALID_ARG;
     }
     if (noutput_items == 0) return 0;
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const int N = h->tab.N;
     int rc = h->d_coef.reserve((size_t)noutput_items * doa::coef_stride(N) * sizeof(double));
@@ -1079,6 +1080,7 @@ int doa_MUSIC_lin_array_work(doa_MUSIC_lin_array_t *h, int noutput_items, const 
         return DOA_ERR_INVALID_ARG;
     }
     if (noutput_items == 0) return 0;
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     const int N = h->tab.N, P = h->tab.P;
     const size_t in_bytes = (size_t)noutput_items * N * N * sizeof(float2);
     const size_t out_bytes = (size_t)noutput_items * P * sizeof(float);
@@ -1101,6 +1103,7 @@ int doa_MUSIC_lin_array_debug(doa_MUSIC_lin_array_t *h, int noutput_items, const
         doa::set_error("MUSIC_lin_array_debug: bad arguments");
         return DOA_ERR_INVALID_ARG;
     }
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     const int N = h->tab.N, P = h->tab.P;
     const size_t in_bytes = (size_t)noutput_items * N * N * sizeof(float2);
     const size_t sp_bytes = (size_t)noutput_items * P * sizeof(float);

@@ -108,6 +108,7 @@ int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput_items, cons
         return DOA_ERR_INVALID_ARG;
     }
     if (noutput_items == 0) return 0;
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     // DOA_PIPE_SKIP=cov,evd,scan: profiling aid that drops stages (outputs are then meaningless)
     unsigned skip = 0;      // read per call so that a profiling script can populate the intermediates first

@@ -381,6 +381,7 @@ int doa_rootMUSIC_linear_array_work_dev(doa_rootMUSIC_linear_array_t *h, int nou
         return DOA_ERR_INVALID_ARG;
     }
     if (noutput_items == 0) return 0;
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     int rc = h->d_coef.reserve((size_t)noutput_items * doa::coef_stride(h->N) * sizeof(double));
     if (rc == DOA_OK) rc = h->d_status.reserve((size_t)noutput_items * sizeof(int));
@@ -401,6 +402,7 @@ int doa_rootMUSIC_linear_array_work(doa_rootMUSIC_linear_array_t *h, int noutput
         return DOA_ERR_INVALID_ARG;
     }
     if (noutput_items == 0) return 0;
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     const size_t in_bytes = (size_t)noutput_items * h->N * h->N * sizeof(float2);
     const size_t out_bytes = (size_t)noutput_items * h->M * sizeof(float);
     int rc = h->d_in.reserve(in_bytes);
