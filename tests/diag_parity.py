@@ -1,7 +1,7 @@
 """GPU diagnostic (not a test): per scenario, how far the HIP MUSIC path and the LAPACK-fp32 oracle
 sit from the fp64 evaluation, for the projector, the null spectrum and the dB spectrum."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path[:0] = [os.path.join(ROOT, "gr-doa_amd", "python"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import numpy as np
 import doa, doa_oracle as oracle

@@ -4,7 +4,7 @@ What "parity" means for this floating-point block (SURVEY §
 output is 10*log10(out/max(out)) with out = 1/Q; the maximum sits at a null of Q where
 Q ~ 1e-5..1e-7 of its full scale is cancellation-dominated in float, so two *correct* fp32
 evaluations (even two BLAS orderings of the reference itself) disagree there by ~1 % and the whole
-normalised spectrum shifts by ~0.01-0.1 dB (measured: tools/diag_parity.py).  The reference's own
+normalised spectrum shifts by ~0.01-0.1 dB (measured: tests/diag_parity.py).  The reference's own
 fp32 rounding is therefore the floor of any comparison against it; what can be pinned tightly is
 the distance to the fp64 evaluation of the same formulas on the same inputs.
 
