@@ -190,6 +190,18 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    # the one exchange step the sharded path has: gather the (tiny) per-snapshot results of the last
+    # batch on every rank — 4 B x batch x world over RCCL/xGMI, once, inside the timed region
+    gather_note = None
+    if dist is not None:
+        torch.cuda.synchronize()
+        try:
+            mine = am[(args.steps - 1) % nbuf].reshape(-1).contiguous()
+            allres = torch.empty(world * mine.numel(), dtype=mine.dtype, device="cuda")
+            dist.all_gather_into_tensor(allres, mine)
+            gather_note = f"all_gather of {mine.numel() * 4} B/rank ok"
+        except Exception as e:                      # never lose the throughput number to the gather
+            gather_note = f"all_gather failed: {e!r}"
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -251,7 +263,7 @@ def main():
                                "batch=4096 snapshots/step, complex fp32, SNR 20 dB",
                    "batch": BATCH, "inputs": N_ANT, "snapshot_size": K_SNAP, "pspectrum_len": P_SPEC,
                    "num_targets": M_SRC, "internal_precision": args.precision, "rotating_batches": nbuf, "hip_streams": n_streams,
-                   "parallelism": f"snapshot-sharded x{world}, no data-path collective"},
+                   "parallelism": f"snapshot-sharded x{world}, no data-path collective (one result all_gather at the end)"},
         "pipeline_gbs": ab["total"] * value / world / 1e9,
         "roofline": {"bound": "hbm", "kernel": "cov_wave_kernel<4,true> (K1 covariance)",
                      "achieved": cov_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cov_gbs / HBM_PEAK_GBS,
@@ -263,6 +275,8 @@ def main():
         },
         "max_angle_error_deg": ang_err,
     }
+    if gather_note:
+        out["result_gather"] = gather_note
     if not args.no_cpu_baseline and world == 1:
         # in a child process: the CPU leg must never be able to take the GPU number down with it
         import subprocess
