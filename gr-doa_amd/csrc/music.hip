@@ -749,6 +749,32 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
     }
 }
 
+// N <= 4 in double: Q(psi) = u0 + 2 sum_l (a_l cos(l psi) - b_l sin(l psi)), u_l = a_l + j b_l, rewritten
+// with cos 2x = 2c^2-1, cos 3x = 4c^3-3c, sin 2x = 2sc, sin 3x = s(4c^2-1) (c = cos psi, s = sin psi) as
+//     Q = A(c) + s B(c),   A = (u0-2a2) + (2a1-6a3) c + 4a2 c^2 + 8a3 c^3,   B = (2b3-2b1) - 4b2 c - 8b3 c^2
+// : 6 fused multiply-adds per angle instead of the 11 of the complex Horner form (the per-item
+// coefficient transform is wave-uniform).  Degree 3 keeps the Chebyshev -> monomial change of basis
+// harmless (|coefficients| grow by <= 8); it is used for the double path only, where its rounding
+// (~1e-15 of the largest term) is far below the 1e-7 the float output resolves.
+template <int N, typename T> struct ChebQ {
+    T a0, a1, a2, a3, b0, b1, b2;
+    __device__ __forceinline__ explicit ChebQ(const T (&c)[2 * N])
+    {
+        const T u0 = c[0];
+        const T x1 = (N > 1) ? c[1] : (T)0, y1 = (N > 1) ? c[2] : (T)0;
+        const T x2 = (N > 2) ? c[3] : (T)0, y2 = (N > 2) ? c[4] : (T)0;
+        const T x3 = (N > 3) ? c[5] : (T)0, y3 = (N > 3) ? c[6] : (T)0;
+        a0 = u0 - 2 * x2; a1 = 2 * x1 - 6 * x3; a2 = 4 * x2; a3 = 8 * x3;
+        b0 = 2 * y3 - 2 * y1; b1 = -4 * y2; b2 = -8 * y3;
+    }
+    __device__ __forceinline__ T operator()(T cs, T sn) const
+    {
+        const T A = fma(fma(fma(a3, cs, a2), cs, a1), cs, a0);
+        const T B = fma(fma(b2, cs, b1), cs, b0);
+        return fma(sn, B, A);
+    }
+};
+
 // The benchmark shape of K4+K5 as its own lean kernel: P == 256*CH exactly (no bounds predicates),
 // num_max_vals == 1 (the peak pick is "first position whose dB equals the maximum", a 6-step DPP
 // integer minimum), compiled polynomial size == the array size (unconditional scalar loads of the
@@ -792,13 +818,24 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
         }
         float out[CH][4];
         float mx = -INFINITY;
+        if constexpr (N <= 4 && sizeof(T) == 8) {
+            const ChebQ<N, T> Q(c);
 #pragma unroll
-        for (int j = 0; j < CH; j++)
+            for (int j = 0; j < CH; j++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                out[j][e] = __builtin_amdgcn_rcpf((float)null_spectrum<N, T>(c, zr[j][e], zi[j][e]));   // 1.0/Q
-                mx = fmaxf(mx, out[j][e]);
-            }
+                for (int e = 0; e < 4; e++) {
+                    out[j][e] = __builtin_amdgcn_rcpf((float)Q(zr[j][e], zi[j][e]));                        // 1.0/Q
+                    mx = fmaxf(mx, out[j][e]);
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    out[j][e] = __builtin_amdgcn_rcpf((float)null_spectrum<N, T>(c, zr[j][e], zi[j][e]));   // 1.0/Q
+                    mx = fmaxf(mx, out[j][e]);
+                }
+        }
         mx = wave_allreduce_max(mx);
         float *row = spec + (size_t)item * P;
         if ((mx > 0.0f) && (mx < INFINITY)) {
