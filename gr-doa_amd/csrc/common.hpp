@@ -115,5 +115,15 @@ __device__ __forceinline__ float wave_allreduce_max(float v)
     v = fmaxf(v, dpp_move<0x143, 0xC>(v, v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+__device__ __forceinline__ float wave_allreduce_min(float v)
+{
+    v = fminf(v, dpp_move<0xB1, 0xF>(v, v));
+    v = fminf(v, dpp_move<0x4E, 0xF>(v, v));
+    v = fminf(v, dpp_move<0x124, 0xF>(v, v));
+    v = fminf(v, dpp_move<0x128, 0xF>(v, v));
+    v = fminf(v, dpp_move<0x142, 0xA>(v, v));
+    v = fminf(v, dpp_move<0x143, 0xC>(v, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 
 }  // namespace doa

@@ -629,7 +629,7 @@ __device__ __forceinline__ float db_from_ratio(float out, float mx, float inv_mx
 // z table (4*CH angles per lane) is loaded once per wave and stays in registers.  With PEAK the
 // find_local_max step (K5) runs on the dB values while they are still in registers, so the spectrum
 // is written once and never read back.
-template <int N, int CH, typename T, bool HAS_Q, bool PEAK, bool NT = false>
+template <int N, int CH, typename T, bool HAS_Q, bool PEAK, bool NT = false, bool ZREG = true>
 __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                          float *__restrict__ spec, float *__restrict__ qout, int P,
                                                          int n_items, const float *__restrict__ xaxis,
@@ -651,14 +651,20 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
         for (int i = threadIdx.x; i < 256 * CH; i += blockDim.x) xs[i] = (i < P) ? xaxis[i] : 0.f;
         __syncthreads();
     }
-    T zr[CH][4], zi[CH][4];
+    // ZREG: the z table of this lane's 4*CH angles stays in registers across items.  Long spectra in
+    // double (CH > 4: more than 128 VGPRs of table) re-read it from L2 per item instead, which is
+    // noise next to their (N-1)-step double Horner.
+    constexpr int ZCH = ZREG ? CH : 1;
+    T zr[ZCH][4], zi[ZCH][4];
+    if constexpr (ZREG) {
 #pragma unroll
-    for (int j = 0; j < CH; j++) {
-        const int i0 = 4 * lane + 256 * j;
+        for (int j = 0; j < CH; j++) {
+            const int i0 = 4 * lane + 256 * j;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            if (i0 < P) { zr[j][e] = ztab[2 * (i0 + e)]; zi[j][e] = ztab[2 * (i0 + e) + 1]; }
-            else { zr[j][e] = 1; zi[j][e] = 0; }
+            for (int e = 0; e < 4; e++) {
+                if (i0 < P) { zr[j][e] = ztab[2 * (i0 + e)]; zi[j][e] = ztab[2 * (i0 + e) + 1]; }
+                else { zr[j][e] = 1; zi[j][e] = 0; }
+            }
         }
     }
     // coefficient records arrive through scalar loads (wave-uniform address); the next item's record
@@ -677,9 +683,17 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
 #pragma unroll
         for (int j = 0; j < CH; j++) {
             const bool live = FULL || ((4 * lane + 256 * j) < P);
+            if constexpr (!ZREG) {
+                const int i0 = 4 * lane + 256 * j;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (live) { zr[0][e] = ztab[2 * (i0 + e)]; zi[0][e] = ztab[2 * (i0 + e) + 1]; }
+                    else { zr[0][e] = 1; zi[0][e] = 0; }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const float q = (float)null_spectrum<N, T>(c, zr[j][e], zi[j][e]);
+                const float q = (float)null_spectrum<N, T>(c, zr[ZREG ? j : 0][e], zi[ZREG ? j : 0][e]);
                 if constexpr (HAS_Q) {
                     if (live) qout[(size_t)item * P + 4 * lane + 256 * j + e] = q;
                 }
@@ -816,47 +830,59 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
 #pragma unroll
             for (int k = 0; k < 2 * N; k++) c_next[k] = coef[(size_t)nxt * (2 * N) + k];
         }
-        float out[CH][4];
-        float mx = -INFINITY;
+        // pass 1: the null spectrum itself (no reciprocal) and its minimum over the item
+        float qf[CH][4];
+        float mn = INFINITY;
         if constexpr (N <= 4 && sizeof(T) == 8) {
             const ChebQ<N, T> Q(c);
 #pragma unroll
             for (int j = 0; j < CH; j++)
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    out[j][e] = __builtin_amdgcn_rcpf((float)Q(zr[j][e], zi[j][e]));                        // 1.0/Q
-                    mx = fmaxf(mx, out[j][e]);
+                    qf[j][e] = (float)Q(zr[j][e], zi[j][e]);
+                    mn = fminf(mn, qf[j][e]);
                 }
         } else {
 #pragma unroll
             for (int j = 0; j < CH; j++)
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    out[j][e] = __builtin_amdgcn_rcpf((float)null_spectrum<N, T>(c, zr[j][e], zi[j][e]));   // 1.0/Q
-                    mx = fmaxf(mx, out[j][e]);
+                    qf[j][e] = (float)null_spectrum<N, T>(c, zr[j][e], zi[j][e]);
+                    mn = fminf(mn, qf[j][e]);
                 }
         }
-        mx = wave_allreduce_max(mx);
+        mn = wave_allreduce_min(mn);
         float *row = spec + (size_t)item * P;
-        if ((mx > 0.0f) && (mx < INFINITY)) {
-            const float inv_mx = __builtin_amdgcn_rcpf(mx);
-            int first_zero = INT_MAX;
+        if ((mn > 0.0f) && (mn < INFINITY)) {
+            // pass 2: 10 log10((1/Q)/max(1/Q)) = -10 log10(2) * log2(Q/Qmin): one transcendental per angle.
+            // 1/Qmin is biased down by 2 ulp so that Qmin/Qmin <= 1 whatever v_rcp rounds to; t <= 1 is
+            // then "this angle holds the maximum" (0 dB exactly, as x/x == 1 in the reference), and the
+            // first such angle of the item is find_local_max's answer for num_max_vals == 1.  The compare
+            // lands in an SGPR pair, so the position search is scalar work beside the vector pipe.
+            const float inv_mn = __builtin_amdgcn_rcpf(mn) * 0.99999976158142f;
+            int pos = INT_MAX;
 #pragma unroll
-            for (int j = CH - 1; j >= 0; j--) {
+            for (int j = 0; j < CH; j++) {
                 float db[4];
 #pragma unroll
-                for (int e = 3; e >= 0; e--) {
-                    const float o = out[j][e];
-                    const float ratio = (o == mx) ? 1.0f : fminf(o * inv_mx, 1.0f);
-                    db[e] = 3.0102999566398120f * __log2f(ratio);
-                    first_zero = (db[e] == 0.0f) ? (4 * lane + 256 * j + e) : first_zero;
+                for (int e = 0; e < 4; e++) {
+                    const float t = qf[j][e] * inv_mn;
+                    const unsigned long long at_max = __builtin_amdgcn_ballot_w64(t <= 1.0f);
+                    const int cand = at_max ? (4 * (int)__builtin_ctzll(at_max) + 256 * j + e) : INT_MAX;
+                    pos = min(pos, cand);
+                    db[e] = fmaf(-3.0102999566398120f, __log2f(fmaxf(t, 1.0f)), 0.0f);     // +0.0 at the maximum
                 }
                 store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(db[0], db[1], db[2], db[3]));
             }
-            const int pos = wave_allreduce_min_int(first_zero);
             if (lane == 0) { pk_val[item] = 0.0f; pk_loc[item] = xs[pos]; }
         } else {
             // rare: follow the general semantics (db_from_ratio, arma index_max) without unrolling
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_amdgcn_rcpf(qf[j][e]));
+            mx = wave_allreduce_max(mx);
             const float inv_mx = __builtin_amdgcn_rcpf(mx);
             float bv = 0.f;
             int bi = INT_MAX;
@@ -918,21 +944,21 @@ struct ScanPeakArgs {           // optional fused K5
     int M = 0;
 };
 
-template <int N, int CH, typename T>
+template <int N, int CH, typename T, bool ZREG = true>
 static void launch_scan_fast(dim3 grid, dim3 block, hipStream_t st, const T *co, const T *z, float *sp, float *q, int P,
                              int n_items, const ScanPeakArgs &pk, int n_ant)
 {
     // three variants: diagnostics (Q out), plain, fused with the peak pick; spectra are write-once ->
     // non-temporal stores in the two production variants
     if (q)
-        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, true, false, false>), grid, block, 0, st, co, z, sp, q, P, n_items,
-                           nullptr, nullptr, nullptr, 0, n_ant);
+        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, true, false, false, ZREG>), grid, block, 0, st, co, z, sp, q, P,
+                           n_items, nullptr, nullptr, nullptr, 0, n_ant);
     else if (pk.val)
-        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, true, true>), grid, block, 0, st, co, z, sp, q, P, n_items,
-                           pk.xaxis, pk.val, pk.loc, pk.M, n_ant);
+        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, true, true, ZREG>), grid, block, 0, st, co, z, sp, q, P,
+                           n_items, pk.xaxis, pk.val, pk.loc, pk.M, n_ant);
     else
-        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, false, true>), grid, block, 0, st, co, z, sp, q, P, n_items,
-                           nullptr, nullptr, nullptr, 0, n_ant);
+        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, false, true, ZREG>), grid, block, 0, st, co, z, sp, q, P,
+                           n_items, nullptr, nullptr, nullptr, 0, n_ant);
 }
 
 // returns true when the fused peak pick ran (fast path only)
@@ -950,7 +976,6 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
     const int max_blocks = 256 * wpc / waves_per_block;
     if (blocks > max_blocks) blocks = max_blocks;
     dim3 grid(blocks), block(waves_per_block * kWave);
-    const int max_ch = (sizeof(T) == 4) ? 16 : 4;        // double z table: 4 chunks fit the register file
     // the lean benchmark-shape kernel (see music_scan_peak1_kernel)
     static const int lean = [] { const char *e = getenv("DOA_SCAN_LEAN"); return e ? atoi(e) : 1; }();
     if (lean && aligned && pk.val && pk.M == 1 && !q && n_ant == N && (P == 256 || P == 512 || P == 1024)) {
@@ -963,14 +988,13 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
         else hipLaunchKernelGGL((music_scan_peak1_kernel<N, 4, T>), lgrid, block, 0, st, co, z, sp, n_items, pk.xaxis, pk.val, pk.loc);
         return true;
     }
-    if (aligned && P <= 256 * max_ch) {
+    if (aligned && P <= 4096) {
+        constexpr bool ZBIG = (sizeof(T) == 4);          // float tables fit the register file up to P = 4096
         if (P <= 256) launch_scan_fast<N, 1, T>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
         else if (P <= 512) launch_scan_fast<N, 2, T>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
         else if (P <= 1024) launch_scan_fast<N, 4, T>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
-        else if constexpr (sizeof(T) == 4) {
-            if (P <= 2048) launch_scan_fast<N, 8, T>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
-            else launch_scan_fast<N, 16, T>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
-        }
+        else if (P <= 2048) launch_scan_fast<N, 8, T, ZBIG>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
+        else launch_scan_fast<N, 16, T, ZBIG>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
         return pk.val != nullptr && q == nullptr;
     }
     hipLaunchKernelGGL((music_scan_generic_kernel<N, T>), grid, block, 0, st, co, z, sp, q, P, n_items, n_ant);
