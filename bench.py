@@ -42,7 +42,52 @@ def algorithmic_bytes():
     evd = N_ANT * N_ANT * 8 * 2                              # K2+K3: 128 + 128
     scan = N_ANT * N_ANT * 8 + P_SPEC * 4                    # K4: 128 + 4096
     peak = P_SPEC * 4 + 2 * M_SRC * 4                        # K5: 4096 + 8
-    return {"cov": cov, "evd": evd, "scan": scan, "peak": peak, "total": cov + evd + scan + peak}
+    # what the fused pipeline actually has to move: K5 runs on the spectrum in registers (no re-read) and the
+    # EVD hands the scan a 2N-double coefficient record instead of the N x N projector
+    rec = 2 * N_ANT * 8
+    fused = cov + (N_ANT * N_ANT * 8 + rec) + (rec + P_SPEC * 4) + 2 * M_SRC * 4
+    return {"cov": cov, "evd": evd, "scan": scan, "peak": peak, "total": cov + evd + scan + peak,
+            "fused_total": fused, "scan_fused": rec + P_SPEC * 4 + 2 * M_SRC * 4}
+
+
+def scan_kernel_roofline(doa, torch, st, batch=262144, reps=10):
+    """The spectrum-scan kernel (K4, with K5 fused) in isolation, at a batch large enough that launch
+    ramp/tail do not dominate (1 GiB of spectra): coefficient records are produced once by a real
+    K1 -> EVD pass over short (64-sample) snapshots, then only the scan launch is repeated."""
+    k_short = 64
+    pipe = doa.music_pipeline(N_ANT, k_short, 0, 0, NORM_SPACING, M_SRC, P_SPEC, batch)
+    s, _ = doa.sim.make_batch_streams_torch(N_ANT, k_short, batch, NORM_SPACING, M_SRC, SNR_DB, seed=77, device="cuda")
+    ptrs = [t.data_ptr() for t in s]
+    cov = torch.empty((batch, N_ANT * N_ANT), dtype=torch.complex64, device="cuda")
+    spec = torch.empty((batch, P_SPEC), dtype=torch.float32, device="cuda")
+    mx = torch.empty((batch, M_SRC), dtype=torch.float32, device="cuda")
+    am = torch.empty((batch, M_SRC), dtype=torch.float32, device="cuda")
+    run = lambda: pipe.work_dev(batch, ptrs, cov.data_ptr(), spec.data_ptr(), mx.data_ptr(), am.data_ptr(), st)
+    run()
+    torch.cuda.synchronize()
+    os.environ["DOA_PIPE_SKIP"] = "cov,evd"          # read per call by the pipeline (diagnostic switch)
+    try:
+        for _ in range(5):
+            run()
+        groups = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record(st)
+            for _ in range(reps):
+                run()
+            e1.record(st)
+            torch.cuda.synchronize()
+            groups.append(e0.elapsed_time(e1) * 1e3 / reps)
+    finally:
+        os.environ.pop("DOA_PIPE_SKIP", None)
+    us = sorted(groups)[len(groups) // 2]             # median of 5 groups of `reps` back-to-back launches
+    nbytes = algorithmic_bytes()["scan_fused"] * batch
+    gbs = nbytes / (us * 1e-6) / 1e9
+    return {"kernel": "music_scan_peak1_kernel<4,4,double> (K4 scan + fused K5 peak), isolated", "batch": batch,
+            "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes, "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "spectra_per_s": batch / (us * 1e-6),
+            "group_avgs_us": groups}
 
 
 def pmc_traffic(kernel_substr):
@@ -130,6 +175,8 @@ def main():
     ap.add_argument("--nbuf", type=int, default=6, help="distinct batches rotated through (defeats L3 residency)")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the steps alternate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scan-roofline", action="store_true",
+                    help="skip the isolated large-batch scan-kernel measurement (keeps rocprof kernel averages clean)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -264,7 +311,8 @@ def main():
                    "batch": BATCH, "inputs": N_ANT, "snapshot_size": K_SNAP, "pspectrum_len": P_SPEC,
                    "num_targets": M_SRC, "internal_precision": args.precision, "rotating_batches": nbuf, "hip_streams": n_streams,
                    "parallelism": f"snapshot-sharded x{world}, no data-path collective (one result all_gather at the end)"},
-        "pipeline_gbs": ab["total"] * value / world / 1e9,
+        "pipeline_gbs": ab["fused_total"] * value / world / 1e9,      # fused algorithmic bytes x rate, per GPU
+        "pipeline_gbs_unfused_accounting": ab["total"] * value / world / 1e9,   # SURVEY 8(d)'s 41 KB/snapshot
         "roofline": {"bound": "hbm", "kernel": "cov_wave_kernel<4,true> (K1 covariance)",
                      "achieved": cov_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cov_gbs / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": ab["cov"] * BATCH, "avg_launch_us": t_cov},
@@ -277,6 +325,11 @@ def main():
     }
     if gather_note:
         out["result_gather"] = gather_note
+    if world == 1 and args.precision == 64 and not args.no_scan_roofline:
+        try:
+            out["scan_kernel_roofline"] = scan_kernel_roofline(doa, torch, st)
+        except Exception as e:                          # secondary figure: never lose the headline to it
+            out["scan_kernel_roofline"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:
         # in a child process: the CPU leg must never be able to take the GPU number down with it
         import subprocess
