@@ -26,7 +26,47 @@ struct doa_music_pipeline {
     doa::PeakTables peaks;
     doa::DevBuf d_cov, d_coef, d_spec, d_scratch, d_gain;
     bool has_gain = false;
+    // host-pointer entry point only: two copy/compute lanes
+    hipStream_t hst[2] = {nullptr, nullptr};
+    doa::DevBuf d_in[2], d_res;
 };
+
+// K1 -> EVD -> scan (+ peak) for n items on `st`; coefficient records at item offset `coef_off` of the
+// handle's workspace (chunks in flight on different streams must not share records).
+static int run_dev(doa_music_pipeline *h, int n, const void *const *d_in, void *cov, void *spec, void *mx, void *am,
+                   size_t item_off, hipStream_t st)
+{
+    // DOA_PIPE_SKIP=cov,evd,scan: profiling aid that drops stages (outputs are then meaningless)
+    unsigned skip = 0;      // read per call so that a profiling script can populate the intermediates first
+    if (const char *e = getenv("DOA_PIPE_SKIP")) {
+        if (strstr(e, "cov")) skip |= 1;
+        if (strstr(e, "evd")) skip |= 2;
+        if (strstr(e, "scan")) skip |= 4;
+    }
+    int rc = DOA_OK;
+    if (!(skip & 1)) rc = doa::launch_autocorrelate(h->N, h->K, h->ovl, h->avg, n, d_in, cov, st,
+                                                     h->has_gain ? h->d_gain.p : nullptr);
+    if (rc != DOA_OK) return rc;
+    const bool dbl = (h->bits == 64);
+    void *coef = static_cast<char *>(h->d_coef.p) + item_off * doa::coef_stride(h->N) * (dbl ? sizeof(double) : sizeof(float));
+    if (!(skip & 2))
+        rc = doa::launch_music_evd(h->N, h->music.M, n, cov, dbl ? nullptr : coef, dbl ? coef : nullptr, nullptr, h->bits, st);
+    if (rc != DOA_OK) return rc;
+    bool peaks_done = false;
+    if (skip & 4) return n;
+    rc = doa::launch_music_scan(h->music, h->bits, n, coef, spec, nullptr, st, &h->peaks, mx, am, &peaks_done);
+    if (rc != DOA_OK) return rc;
+    if (peaks_done) return n;
+    if (doa::find_local_max_fast_ok(h->peaks.L, spec)) {
+        rc = doa::launch_find_local_max(h->peaks, n, spec, mx, am, st);
+    } else {
+        rc = h->d_scratch.reserve((size_t)h->max_batch * h->peaks.L);
+        if (rc == DOA_OK)
+            rc = doa::launch_find_local_max_serial(h->peaks, n, spec, mx, am,
+                                                   static_cast<char *>(h->d_scratch.p) + item_off * h->peaks.L, st);
+    }
+    return rc == DOA_OK ? n : rc;
+}
 
 extern "C" {
 
@@ -72,6 +112,10 @@ void doa_music_pipeline_destroy(doa_music_pipeline_t *h)
     h->music.release();
     h->peaks.release();
     h->d_cov.release(); h->d_coef.release(); h->d_spec.release(); h->d_scratch.release(); h->d_gain.release();
+    h->d_res.release();
+    for (auto &b : h->d_in) b.release();
+    for (auto st : h->hst)
+        if (st) (void)hipStreamDestroy(st);
     delete h;
 }
 
@@ -109,40 +153,76 @@ int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput_items, cons
     }
     if (noutput_items == 0) return 0;
     if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
-    hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    // DOA_PIPE_SKIP=cov,evd,scan: profiling aid that drops stages (outputs are then meaningless)
-    unsigned skip = 0;      // read per call so that a profiling script can populate the intermediates first
-    if (const char *e = getenv("DOA_PIPE_SKIP")) {
-        if (strstr(e, "cov")) skip |= 1;
-        if (strstr(e, "evd")) skip |= 2;
-        if (strstr(e, "scan")) skip |= 4;
-    }
     void *cov = d_cov_out ? d_cov_out : h->d_cov.p;
     void *spec = d_spectrum_out ? d_spectrum_out : h->d_spec.p;
-    int rc = DOA_OK;
-    if (!(skip & 1)) rc = doa::launch_autocorrelate(h->N, h->K, h->ovl, h->avg, noutput_items, d_input_items, cov, st,
-                                                     h->has_gain ? h->d_gain.p : nullptr);
-    if (rc != DOA_OK) return rc;
-    const bool dbl = (h->bits == 64);
-    if (!(skip & 2))
-        rc = doa::launch_music_evd(h->N, h->music.M, noutput_items, cov, dbl ? nullptr : h->d_coef.p,
-                                   dbl ? h->d_coef.p : nullptr, nullptr, h->bits, st);
-    if (rc != DOA_OK) return rc;
-    bool peaks_done = false;
-    if (skip & 4) return noutput_items;
-    rc = doa::launch_music_scan(h->music, h->bits, noutput_items, h->d_coef.p, spec, nullptr, st, &h->peaks, d_max_out,
-                                d_argmax_out, &peaks_done);
-    if (rc != DOA_OK) return rc;
-    if (peaks_done) return noutput_items;
-    if (doa::find_local_max_fast_ok(h->peaks.L, spec)) {
-        rc = doa::launch_find_local_max(h->peaks, noutput_items, spec, d_max_out, d_argmax_out, st);
-    } else {
-        rc = h->d_scratch.reserve((size_t)h->max_batch * h->peaks.L);
-        if (rc == DOA_OK)
-            rc = doa::launch_find_local_max_serial(h->peaks, noutput_items, spec, d_max_out, d_argmax_out,
-                                                   h->d_scratch.p, st);
+    return run_dev(h, noutput_items, d_input_items, cov, spec, d_max_out, d_argmax_out, 0,
+                   static_cast<hipStream_t>(hip_stream));
+}
+
+int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const void *const *input_items, void *cov_out,
+                            void *spectrum_out, void *max_out, void *argmax_out)
+{
+    doa::clear_error();
+    if (!h || noutput_items < 0 || !input_items || (noutput_items > 0 && (!max_out || !argmax_out))) {
+        doa::set_error("music_pipeline_work: bad arguments");
+        return DOA_ERR_INVALID_ARG;
     }
-    return rc == DOA_OK ? noutput_items : rc;
+    if (noutput_items > h->max_batch) {
+        doa::set_error("music_pipeline_work: noutput_items=%d exceeds max_batch=%d", noutput_items, h->max_batch);
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (noutput_items == 0) return 0;
+    const int N = h->N, M = h->music.M, P = h->peaks.L;
+    for (int k = 0; k < N; k++)
+        if (!input_items[k]) { doa::set_error("music_pipeline_work: input_items[%d] is NULL", k); return DOA_ERR_INVALID_ARG; }
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
+    for (auto &st : h->hst)
+        if (!st) DOA_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    // Chunks of ~32 MiB of new samples alternate over two streams: while one chunk's results travel back
+    // the next chunk's samples travel in (PCIe is full duplex; the kernels themselves are ~1 % of a
+    // chunk's transfer time).  The overlap needs page-locked caller buffers; pageable ones still work.
+    const size_t nonoverlap = (size_t)(h->K - h->ovl);
+    size_t chunk = ((size_t)32 << 20) / (nonoverlap * N * sizeof(float2));
+    chunk = chunk < 1 ? 1 : (chunk > (size_t)noutput_items ? (size_t)noutput_items : chunk);
+    const size_t span_max = (chunk - 1) * nonoverlap + h->K;
+    const size_t span_al = (span_max + 1) & ~(size_t)1;          // every stream stays 16-B aligned on the device
+    int rc = h->d_res.reserve((size_t)h->max_batch * M * 2 * sizeof(float));
+    for (auto &b : h->d_in)
+        if (rc == DOA_OK) rc = b.reserve(span_al * N * sizeof(float2));
+    if (rc != DOA_OK) return rc;
+    float *d_mx = h->d_res.as<float>(), *d_am = d_mx + (size_t)h->max_batch * M;
+    int lane = 0;
+    for (size_t s0 = 0; s0 < (size_t)noutput_items; s0 += chunk, lane ^= 1) {
+        const size_t n = ((size_t)noutput_items - s0 < chunk) ? (size_t)noutput_items - s0 : chunk;
+        const size_t span = (n - 1) * nonoverlap + h->K;
+        hipStream_t st = h->hst[lane];
+        const void *d_ptrs[DOA_MAX_ANT_ELE];
+        for (int k = 0; k < N; k++) {
+            float2 *dst = h->d_in[lane].as<float2>() + k * span_al;
+            const float2 *src = static_cast<const float2 *>(input_items[k]) + s0 * nonoverlap;
+            DOA_HIP_TRY(hipMemcpyAsync(dst, src, span * sizeof(float2), hipMemcpyHostToDevice, st));
+            d_ptrs[k] = dst;
+        }
+        float2 *cov = h->d_cov.as<float2>() + s0 * N * N;
+        float *spec = h->d_spec.as<float>() + s0 * P;
+        rc = run_dev(h, (int)n, d_ptrs, cov, spec, d_mx + s0 * M, d_am + s0 * M, s0, st);
+        if (rc < 0) break;
+        if (cov_out)
+            DOA_HIP_TRY(hipMemcpyAsync(static_cast<float2 *>(cov_out) + s0 * N * N, cov, n * N * N * sizeof(float2),
+                                       hipMemcpyDeviceToHost, st));
+        if (spectrum_out)
+            DOA_HIP_TRY(hipMemcpyAsync(static_cast<float *>(spectrum_out) + s0 * P, spec, n * P * sizeof(float),
+                                       hipMemcpyDeviceToHost, st));
+        DOA_HIP_TRY(hipMemcpyAsync(static_cast<float *>(max_out) + s0 * M, d_mx + s0 * M, n * M * sizeof(float),
+                                   hipMemcpyDeviceToHost, st));
+        DOA_HIP_TRY(hipMemcpyAsync(static_cast<float *>(argmax_out) + s0 * M, d_am + s0 * M, n * M * sizeof(float),
+                                   hipMemcpyDeviceToHost, st));
+    }
+    for (auto st : h->hst) {
+        const hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess && rc >= 0) { doa::set_error("music_pipeline_work: %s", hipGetErrorString(e)); rc = DOA_ERR_HIP; }
+    }
+    return rc < 0 ? rc : noutput_items;
 }
 
 }  // extern "C"

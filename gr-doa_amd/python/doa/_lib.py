@@ -97,6 +97,7 @@ SIGNATURES = {
     "doa_music_pipeline_create": (_vp, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]),
     "doa_music_pipeline_destroy": (None, [_vp]),
     "doa_music_pipeline_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp, _vp]),
+    "doa_music_pipeline_work": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -310,6 +310,31 @@ class music_pipeline(_Block):
             C.c_void_p(int(d_spec_ptr or 0)), C.c_void_p(int(d_max_ptr)), C.c_void_p(int(d_argmax_ptr)),
             _stream_ptr(stream)))
 
+    def input_span(self, noutput_items) -> int:
+        n = int(noutput_items)
+        return 0 if n <= 0 else (n - 1) * (self.snapshot_size - self.overlap_size) + self.snapshot_size
+
+    def work(self, noutput_items, input_items, max_out, argmax_out, cov_out=None, spectrum_out=None) -> int:
+        """Host buffers in, host buffers out (numpy): input_items[k] = complex64 stream k starting at
+        its first history sample; max_out / argmax_out [>=n, M] float32; cov_out [>=n, N*N] complex64
+        and spectrum_out [>=n, P] float32 are optional."""
+        n = int(noutput_items)
+        span = self.input_span(n)
+        arrs = []
+        for k in range(self.inputs):
+            a = np.ascontiguousarray(input_items[k], dtype=_C64)
+            if a.shape[0] < span:
+                raise ValueError(f"input {k}: {a.shape[0]} samples, need {span}")
+            arrs.append(a)
+        for o, dt, per in ((max_out, _F32, self.num_targets), (argmax_out, _F32, self.num_targets),
+                           (cov_out, _C64, self.inputs ** 2), (spectrum_out, _F32, self.pspectrum_len)):
+            if o is not None:
+                assert o.dtype == dt and o.flags.c_contiguous and o.size >= n * per
+        none = C.c_void_p(0)
+        return check(lib.doa_music_pipeline_work(
+            self._h, n, ptr_array([a.ctypes.data for a in arrs]), none if cov_out is None else _vp(cov_out),
+            none if spectrum_out is None else _vp(spectrum_out), _vp(max_out), _vp(argmax_out)))
+
 
 def set_internal_precision(bits: int) -> None:
     check(lib.doa_set_internal_precision(int(bits)))

@@ -234,6 +234,16 @@ DOA_HIP_API int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput
                                             const void *const *d_input_items, void *d_cov_out,
                                             void *d_spectrum_out, void *d_max_out,
                                             void *d_argmax_out, void *hip_stream);
+/* The same three blocks on HOST buffers (the layouts the GNU Radio scheduler hands to the blocks'
+ * work(): input_items[k] = stream k, doa_autocorrelate_input_span(noutput_items) samples; outputs
+ * noutput_items items each).  cov_out and spectrum_out may be NULL: only the 2*num_targets floats
+ * per snapshot then cross PCIe on the way back.  Samples are moved in ~32 MiB chunks alternating over
+ * two streams owned by the handle (transfers of neighbouring chunks overlap when the caller's
+ * buffers are page-locked); returns when every output has landed.  This path is PCIe-bound
+ * (N*(snapshot-overlap)*8 B per snapshot in), see DESIGN.md §6. */
+DOA_HIP_API int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items,
+                                        const void *const *input_items, void *cov_out,
+                                        void *spectrum_out, void *max_out, void *argmax_out);
 
 #ifdef __cplusplus
 }

@@ -89,3 +89,57 @@ def test_pipeline_rejects_oversized_batch():
     pipe = doa.music_pipeline(4, 64, 0, 0, 0.5, 1, 64, max_batch=8)
     with pytest.raises(doa.DoaError):
         pipe.work_dev(9, [1, 1, 1, 1], 0, 0, 1, 1, None)
+
+
+@pytest.mark.parametrize("name", ["bench_cfg2", "grc_music_sim", "three_ant_fb", "five_ant"])
+def test_pipeline_host_entry_equals_device_entry(name):
+    # doa_music_pipeline_work (host buffers, what a GNU Radio hier block would call) against the
+    # device-pointer entry point on the same samples: bit for bit, optional outputs optional
+    c, x = make_input(name)
+    N, M, P, n = c["N"], c["M"], c["P"], c["n"]
+    pipe = doa.music_pipeline(N, c["K"], c["ovl"], c["fb"], c["d"], M, P, max_batch=n)
+    streams = [_dev(x[k]) for k in range(N)]
+    cov = torch.empty((n, N * N), dtype=torch.complex64, device="cuda")
+    spec = torch.empty((n, P), dtype=torch.float32, device="cuda")
+    mx = torch.empty((n, M), dtype=torch.float32, device="cuda")
+    am = torch.empty((n, M), dtype=torch.float32, device="cuda")
+    pipe.work_dev(n, [s.data_ptr() for s in streams], cov.data_ptr(), spec.data_ptr(), mx.data_ptr(), am.data_ptr(),
+                  torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    h_mx, h_am = np.empty((n, M), np.float32), np.empty((n, M), np.float32)
+    h_cov, h_spec = np.empty((n, N * N), np.complex64), np.empty((n, P), np.float32)
+    assert pipe.work(n, [x[k] for k in range(N)], h_mx, h_am, cov_out=h_cov, spectrum_out=h_spec) == n
+    assert np.array_equal(h_cov, cov.cpu().numpy()) and np.array_equal(h_spec, spec.cpu().numpy())
+    assert np.array_equal(h_mx, mx.cpu().numpy()) and np.array_equal(h_am, am.cpu().numpy())
+    a_mx, a_am = np.full((n, M), np.nan, np.float32), np.full((n, M), np.nan, np.float32)
+    assert pipe.work(n - 1, [x[k] for k in range(N)], a_mx, a_am) == n - 1           # angles only, fewer items
+    assert np.array_equal(a_mx[:n - 1], h_mx[:n - 1]) and np.array_equal(a_am[:n - 1], h_am[:n - 1])
+    assert np.isnan(a_mx[n - 1]).all()
+    with pytest.raises(ValueError):
+        pipe.work(n, [x[k][:-1] for k in range(N)], h_mx, h_am)
+    with pytest.raises(doa.DoaError):
+        pipe.work(n + 1, [np.zeros(x.shape[1] + c["K"], np.complex64)] * N, np.empty((n + 1, M), np.float32),
+                  np.empty((n + 1, M), np.float32))
+
+
+@pytest.mark.parametrize("K,ovl,fb,M", [(1024, 0, 0, 1), (2048, 512, 1, 2)])
+def test_pipeline_host_entry_multi_chunk(K, ovl, fb, M):
+    # enough snapshots for several 32 MiB transfer chunks on both copy/compute lanes, with and without
+    # overlapping windows (a chunk's first window re-reads the previous chunk's last `ovl` samples)
+    N, P, d = 4, 1024, 0.5
+    n = 2 * ((32 << 20) // ((K - ovl) * N * 8)) + 301
+    T = (n - 1) * (K - ovl) + K
+    x = doa.sim.make_streams(N, T, [40.0, 115.0][:M], d, snr_db=15.0, seed=5)
+    pipe = doa.music_pipeline(N, K, ovl, fb, d, M, P, max_batch=n)
+    h_mx, h_am = np.empty((n, M), np.float32), np.empty((n, M), np.float32)
+    h_spec = np.empty((n, P), np.float32)
+    assert pipe.work(n, [x[k] for k in range(N)], h_mx, h_am, spectrum_out=h_spec) == n
+    streams = [_dev(x[k]) for k in range(N)]
+    spec = torch.empty((n, P), dtype=torch.float32, device="cuda")
+    mx = torch.empty((n, M), dtype=torch.float32, device="cuda")
+    am = torch.empty((n, M), dtype=torch.float32, device="cuda")
+    pipe.work_dev(n, [s.data_ptr() for s in streams], 0, spec.data_ptr(), mx.data_ptr(), am.data_ptr(),
+                  torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(h_spec, spec.cpu().numpy())
+    assert np.array_equal(h_mx, mx.cpu().numpy()) and np.array_equal(h_am, am.cpu().numpy())

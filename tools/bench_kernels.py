@@ -94,6 +94,28 @@ if "mpipe" in args.stages:
     res["mpipe_streams"] = S
     res["mpipe_us"] = (min(ts), sorted(ts)[2])
     res["mpipe_snapshots_per_s"] = B / min(ts) * 1e6
+if "host" in args.stages:
+    # the host-pointer entry point (PCIe-inclusive): pageable vs page-locked caller buffers,
+    # angles only vs spectrum returned as well; also the GNU Radio-sized call (8 items)
+    import time
+    import numpy as np
+    for pinned in (False, True):
+        hx = [torch.view_as_complex(torch.randn((B * K, 2), dtype=torch.float32)) for _ in range(N)]
+        h_mx, h_am = torch.empty((B, M)), torch.empty((B, M))
+        h_spec = torch.empty((B, P))
+        if pinned:
+            hx = [t.pin_memory() for t in hx]; h_mx, h_am, h_spec = h_mx.pin_memory(), h_am.pin_memory(), h_spec.pin_memory()
+        xs = [t.numpy() for t in hx]
+        for what, sp in (("angles", None), ("spectrum", h_spec.numpy())):
+            for nit in (B, 8):
+                pipe.work(nit, xs, h_mx.numpy(), h_am.numpy(), spectrum_out=sp)
+                reps = 5 if nit == B else 200
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    pipe.work(nit, xs, h_mx.numpy(), h_am.numpy(), spectrum_out=sp)
+                dt = (time.perf_counter() - t0) / reps
+                res[f"host_{'pinned' if pinned else 'pageable'}_{what}_n{nit}"] = {"us_per_call": dt * 1e6, "snapshots_per_s": nit / dt,
+                                                                              "GBs_in": nit * N * K * 8 / dt / 1e9}
 if args.ablate:
     import time
     S = args.streams
