@@ -98,6 +98,16 @@ SIGNATURES = {
     "doa_music_pipeline_destroy": (None, [_vp]),
     "doa_music_pipeline_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp, _vp]),
     "doa_music_pipeline_work": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp]),
+    "doa_compass_mean_create": (_vp, [C.c_int]),
+    "doa_compass_mean_destroy": (None, [_vp]),
+    "doa_compass_mean_work": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "doa_compass_mean_work_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "doa_sim_source_create": (_vp, [C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, _vp, C.c_float, C.c_ulonglong]),
+    "doa_sim_source_destroy": (None, [_vp]),
+    "doa_sim_source_seek": (C.c_int, [_vp, C.c_longlong]),
+    "doa_sim_source_tell": (C.c_longlong, [_vp]),
+    "doa_sim_source_work": (C.c_int, [_vp, C.c_int, _vpp]),
+    "doa_sim_source_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -336,6 +336,79 @@ class music_pipeline(_Block):
             none if spectrum_out is None else _vp(spectrum_out), _vp(max_out), _vp(argmax_out)))
 
 
+class compass_mean(_Block):
+    """blocks.vector_to_streams(float, num_streams) + the averaging step of doa.compass
+    (reference python/compass.py:134-136: next_angle = numpy.mean(input_items[0]) per work call),
+    on the device.  The dial/LCD GUI of the compass is not reproduced."""
+
+    _destroy = staticmethod(lib.doa_compass_mean_destroy)
+
+    def __init__(self, num_streams):
+        super().__init__()
+        self.num_streams = int(num_streams)
+        self._h = check_handle(lib.doa_compass_mean_create(self.num_streams), "compass_mean")
+        self.next_angle = np.full(self.num_streams, np.nan, _F32)
+        self.in_sig = [(_F32, self.num_streams)]
+        self.out_sig = []
+
+    def work(self, ninput_items, input_items, output_items=None) -> int:
+        n = int(ninput_items)
+        a = np.ascontiguousarray(input_items[0], dtype=_F32)
+        assert a.size >= n * self.num_streams
+        return check(lib.doa_compass_mean_work(self._h, n, _vp(a), _vp(self.next_angle)))
+
+    def work_dev(self, ninput_items, d_in_ptr, d_next_angle_ptr, stream=None) -> int:
+        return check(lib.doa_compass_mean_work_dev(self._h, int(ninput_items), C.c_void_p(int(d_in_ptr or 0)),
+                                                   C.c_void_p(int(d_next_angle_ptr)), _stream_ptr(stream)))
+
+
+class sim_source(_Block):
+    """The signal front end of apps/run_MUSIC_lin_array_simulation.py (:66-74, :204-210) as one
+    device-side generator: tones + per-source Gaussian noise through the array manifold, plus
+    optional per-antenna noise.  tone_freq in cycles/sample."""
+
+    _destroy = staticmethod(lib.doa_sim_source_destroy)
+
+    def __init__(self, num_ant_ele, norm_spacing, theta_deg, tone_freq, tone_ampl=None, source_noise_ampl=None,
+                 antenna_noise_sigma=0.0, seed=0):
+        super().__init__()
+        th = np.ascontiguousarray(np.atleast_1d(theta_deg), dtype=_F32)
+        fr = np.ascontiguousarray(np.atleast_1d(tone_freq), dtype=np.float64)
+        M = th.shape[0]
+        if fr.shape[0] != M:
+            raise ValueError("tone_freq and theta_deg differ in length")
+        opt = []
+        for v in (tone_ampl, source_noise_ampl):
+            if v is None:
+                opt.append(None)
+            else:
+                v = np.ascontiguousarray(np.atleast_1d(v), dtype=_F32)
+                if v.shape[0] != M:
+                    raise ValueError("per-source arrays differ in length")
+                opt.append(v)
+        self.num_ant_ele, self.num_sources = int(num_ant_ele), int(M)
+        none = C.c_void_p(0)
+        self._h = check_handle(lib.doa_sim_source_create(
+            self.num_ant_ele, self.num_sources, float(norm_spacing), _vp(th), _vp(fr),
+            none if opt[0] is None else _vp(opt[0]), none if opt[1] is None else _vp(opt[1]),
+            float(antenna_noise_sigma), int(seed) & 0xFFFFFFFFFFFFFFFF), "sim_source")
+
+    def seek(self, sample_index) -> None:
+        check(lib.doa_sim_source_seek(self._h, int(sample_index)))
+
+    def tell(self) -> int:
+        return int(lib.doa_sim_source_tell(self._h))
+
+    def work(self, noutput_items, output_items) -> int:
+        n = int(noutput_items)
+        for o in output_items[:self.num_ant_ele]:
+            assert o.dtype == _C64 and o.flags.c_contiguous and o.size >= n
+        return check(lib.doa_sim_source_work(self._h, n, ptr_array([o.ctypes.data for o in output_items[:self.num_ant_ele]])))
+
+    def work_dev(self, noutput_items, d_output_ptrs, stream=None) -> int:
+        return check(lib.doa_sim_source_work_dev(self._h, int(noutput_items), ptr_array(d_output_ptrs), _stream_ptr(stream)))
+
+
 def set_internal_precision(bits: int) -> None:
     check(lib.doa_set_internal_precision(int(bits)))
 

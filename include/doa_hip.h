@@ -245,6 +245,52 @@ DOA_HIP_API int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_ite
                                         const void *const *input_items, void *cov_out,
                                         void *spectrum_out, void *max_out, void *argmax_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * compass_mean — blocks.vector_to_streams(float, num_streams) + the averaging of doa.compass
+ *   (reference python/compass.py:134-136: next_angle = numpy.mean(input_items[0]) over the items of
+ *   one work call; wiring apps/run_MUSIC_lin_array_simulation.py:199,236-239).
+ *   input item = num_streams floats (port 1 of find_local_max); output = num_streams floats, the
+ *   mean of each de-interleaved stream over the ninput_items items (NaN for 0 items, as numpy).
+ *   Returns the number of items consumed (= ninput_items).  The compass GUI is out of scope.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct doa_compass_mean doa_compass_mean_t;
+
+DOA_HIP_API doa_compass_mean_t *doa_compass_mean_create(int num_streams);
+DOA_HIP_API void doa_compass_mean_destroy(doa_compass_mean_t *h);
+DOA_HIP_API int doa_compass_mean_work(doa_compass_mean_t *h, int ninput_items,
+                                      const void *input_items0, float *next_angle);
+DOA_HIP_API int doa_compass_mean_work_dev(doa_compass_mean_t *h, int ninput_items,
+                                          const void *d_input_items0, float *d_next_angle,
+                                          void *hip_stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * sim_source — the signal front end of the simulation flowgraphs as one generator
+ *   (reference apps/run_MUSIC_lin_array_simulation.py:66-74 array manifold, :204-210 sig_source_c +
+ *   noise_source_c per source -> add -> multiply_matrix_cc):
+ *     x_n[t] = sum_m A[n][m] (tone_ampl[m] e^{j 2 pi tone_freq[m] t} + source_noise_ampl[m] (g + j g'))
+ *              + antenna_noise_sigma (g + j g') / sqrt(2)
+ *   tone_freq in cycles per sample; tone_ampl / source_noise_ampl may be NULL (1 / 0).  Noise is
+ *   Philox4x32-10 keyed by `seed` (counter = sample-pair index and noise stream), so sample ranges
+ *   are reproducible independently of call boundaries; it is not GNU Radio's generator.
+ *   work produces the next noutput_items samples of the num_ant_ele output streams (complex64 each);
+ *   every call except the last of a run must ask for an even number (seek positions are even).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct doa_sim_source doa_sim_source_t;
+
+DOA_HIP_API doa_sim_source_t *doa_sim_source_create(int num_ant_ele, int num_sources,
+                                                    float norm_spacing, const float *theta_deg,
+                                                    const double *tone_freq, const float *tone_ampl,
+                                                    const float *source_noise_ampl,
+                                                    float antenna_noise_sigma,
+                                                    unsigned long long seed);
+DOA_HIP_API void doa_sim_source_destroy(doa_sim_source_t *h);
+DOA_HIP_API int doa_sim_source_seek(doa_sim_source_t *h, long long sample_index);
+DOA_HIP_API long long doa_sim_source_tell(const doa_sim_source_t *h);
+DOA_HIP_API int doa_sim_source_work(doa_sim_source_t *h, int noutput_items,
+                                    void *const *output_items);
+DOA_HIP_API int doa_sim_source_work_dev(doa_sim_source_t *h, int noutput_items,
+                                        void *const *d_output_items, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -449,3 +449,85 @@ def music_pipeline(input_items: np.ndarray, snapshot_size: int, overlap_size: in
     spec = music_lin_array(R, norm_spacing, num_targets, N, pspectrum_len, precision)
     vals, locs = find_local_max(spec.astype(_F32), num_targets, pspectrum_len, 0.0, 180.0)
     return R, spec, vals, locs
+
+
+# ---- downstream of the path: vector_to_streams + compass averaging ------------
+def compass_mean(argmax_items: np.ndarray, num_streams: int) -> np.ndarray:
+    """blocks.vector_to_streams(float, num_streams) followed by one compass per stream, each doing
+    `numpy.mean(input_items[0])` over the items of the work call (python/compass.py:134-136; wiring
+    apps/run_MUSIC_lin_array_simulation.py:199,236-239).  numpy.mean on the float32 stream, exactly
+    as the reference calls it."""
+    a = np.asarray(argmax_items, dtype=np.float32).reshape(-1, num_streams)
+    if a.shape[0] == 0:
+        return np.full(num_streams, np.nan, np.float32)
+    return np.array([np.mean(np.ascontiguousarray(a[:, m])) for m in range(num_streams)], dtype=np.float32)
+
+
+# ---- upstream of the path: the simulation flowgraphs' signal front end (SURVEY §8f row 4) --------
+def philox4x32_10(counter: np.ndarray, key) -> np.ndarray:
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11).
+    counter [..., 4] uint32, key (k0, k1) -> [..., 4] uint32.  Pinned by the Random123 known-answer
+    vectors in tests/test_cpu_oracle_pins.py."""
+    c = np.array(counter, dtype=np.uint64, copy=True)
+    k0, k1 = np.uint64(int(key[0]) & 0xFFFFFFFF), np.uint64(int(key[1]) & 0xFFFFFFFF)
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    W0, W1 = np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+    mask = np.uint64(0xFFFFFFFF)
+    s32 = np.uint64(32)
+    for _ in range(10):
+        p0 = M0 * c[..., 0]
+        p1 = M1 * c[..., 2]
+        n0 = (p1 >> s32) ^ c[..., 1] ^ k0
+        n2 = (p0 >> s32) ^ c[..., 3] ^ k1
+        c = np.stack([n0, p1 & mask, n2, p0 & mask], axis=-1)
+        k0 = (k0 + W0) & mask
+        k1 = (k1 + W1) & mask
+    return c.astype(np.uint32)
+
+
+def _box_muller(w0: np.ndarray, w1: np.ndarray) -> np.ndarray:
+    u1 = ((w0 >> np.uint32(9)).astype(np.float64) + 0.5) * 2.0 ** -23
+    u2 = ((w1 >> np.uint32(9)).astype(np.float64) + 0.5) * 2.0 ** -23
+    r = np.sqrt(-2.0 * np.log(u1))
+    return r * np.cos(2.0 * np.pi * u2) + 1j * r * np.sin(2.0 * np.pi * u2)
+
+
+def sim_noise_stream(seed: int, stream_id: int, first_sample: int, n_samples: int) -> np.ndarray:
+    """Complex standard-normal pairs (g + j g') of one noise stream: Philox counter =
+    (sample-pair index lo, hi, stream id, 0), key = seed; words (0,1) -> sample 2i, (2,3) -> 2i+1."""
+    assert first_sample % 2 == 0
+    pairs = np.arange(first_sample // 2, (first_sample + n_samples + 1) // 2, dtype=np.uint64)
+    ctr = np.stack([pairs & np.uint64(0xFFFFFFFF), pairs >> np.uint64(32),
+                    np.full_like(pairs, stream_id), np.zeros_like(pairs)], axis=-1)
+    r = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    g = np.stack([_box_muller(r[:, 0], r[:, 1]), _box_muller(r[:, 2], r[:, 3])], axis=-1).reshape(-1)
+    return g[:n_samples]
+
+
+def sim_source(num_ant_ele: int, norm_spacing: float, theta_deg, tone_freq, n_samples: int, tone_ampl=None,
+               source_noise_ampl=None, antenna_noise_sigma: float = 0.0, seed: int = 0,
+               first_sample: int = 0) -> np.ndarray:
+    """sig_source_c + noise_source_c per source -> add -> multiply_matrix_cc(array manifold)
+    (apps/run_MUSIC_lin_array_simulation.py:66-74,204-210), plus optional per-antenna noise
+    sigma (g + j g')/sqrt(2) (music_test_input_gen.m:97-107).  float64 evaluation -> complex64."""
+    th = np.deg2rad(np.atleast_1d(np.asarray(theta_deg, dtype=np.float32)).astype(np.float64))
+    f = np.atleast_1d(np.asarray(tone_freq, dtype=np.float64))
+    M = th.shape[0]
+    amp = np.ones(M) if tone_ampl is None else np.atleast_1d(np.asarray(tone_ampl, np.float32)).astype(np.float64)
+    sn = np.zeros(M) if source_noise_ampl is None else np.atleast_1d(np.asarray(source_noise_ampl, np.float32)).astype(np.float64)
+    d = float(np.float32(norm_spacing))
+    loc = d * ((num_ant_ele - 1) / 2.0 - np.arange(num_ant_ele))                       # :70
+    A = np.exp(-2j * np.pi * np.cos(th)[None, :] * loc[:, None]).astype(np.complex64).astype(np.complex128)
+    t = np.arange(first_sample, first_sample + n_samples, dtype=np.float64)
+    src = np.empty((M, n_samples), np.complex128)
+    for m in range(M):
+        cyc = f[m] * t
+        src[m] = amp[m] * np.exp(2j * np.pi * (cyc - np.floor(cyc)))
+        if sn[m] != 0.0:
+            src[m] += sn[m] * sim_noise_stream(seed, m, first_sample, n_samples)
+    x = A @ src
+    sigma = float(np.float32(antenna_noise_sigma))
+    if sigma != 0.0:
+        for n in range(num_ant_ele):
+            x[n] += sigma / np.sqrt(2.0) * sim_noise_stream(seed, M + n, first_sample, n_samples)
+    return np.ascontiguousarray(x.astype(np.complex64))

@@ -163,3 +163,41 @@ def test_simulation_flowgraph_scenario():
     _, spec, vals, locs = oracle.music_pipeline(x, K, ovl, 1, 0.4, 2, P, precision="f64")
     assert np.all(np.abs(np.sort(locs, axis=1) - np.array([30.0, 123.0])[None, :]) <= 0.2)
     assert np.all(np.diff(vals, axis=1) <= 0) and np.all(np.diff(locs, axis=1) <= 0)
+
+
+def test_philox4x32_10_known_answers():
+    # Random123 kat_vectors (philox4x32 10 rounds): zero, all-ones and the pi-digits vectors
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kats:
+        got = oracle.philox4x32_10(np.array(ctr, dtype=np.uint32), key)
+        assert [int(v) for v in got] == list(want)
+
+
+def test_sim_source_oracle_has_the_flowgraph_statistics():
+    # the generator restatement against the model it claims: tones through the manifold give the
+    # covariance A diag(p) A^H (+ noise terms), and the noise streams are unit-variance, uncorrelated
+    N, d, thetas, freqs = 4, 0.4, [30.0, 123.0], [0.03125, 0.0625]
+    T = 1 << 15
+    x = oracle.sim_source(N, d, thetas, freqs, T, None, [0.05, 0.1], 0.2, seed=11).astype(np.complex128)
+    R = x @ x.conj().T / T
+    th = np.deg2rad(np.array(thetas))
+    loc = d * ((N - 1) / 2.0 - np.arange(N))
+    A = np.exp(-2j * np.pi * np.cos(th)[None, :] * loc[:, None])
+    p = np.array([1 + 2 * 0.05 ** 2, 1 + 2 * 0.1 ** 2])          # tone power + complex noise of variance 2 a^2
+    want = A @ np.diag(p) @ A.conj().T + 0.2 ** 2 * np.eye(N)
+    assert np.abs(R - want).max() <= 0.02
+    g = oracle.sim_noise_stream(11, 3, 0, 1 << 16)
+    assert abs(g.real.std() - 1) < 0.01 and abs(g.imag.std() - 1) < 0.01 and abs(np.mean(g * g)) < 0.02
+    h = oracle.sim_noise_stream(11, 4, 0, 1 << 16)
+    assert abs(np.mean(g * h.conj())) < 0.02
+    # independent of where a range starts
+    assert np.array_equal(oracle.sim_noise_stream(11, 3, 1000, 64), g[1000:1064])
+
+
+def test_compass_mean_oracle():
+    a = np.array([[10.0, 100.0], [20.0, 110.0], [60.0, 150.0]], np.float32)
+    assert np.array_equal(oracle.compass_mean(a, 2), np.array([30.0, 120.0], np.float32))
+    assert np.isnan(oracle.compass_mean(np.empty((0, 3), np.float32), 3)).all()
