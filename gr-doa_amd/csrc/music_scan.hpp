@@ -1,0 +1,24 @@
+// music_scan.hpp — interface between music.hip (dispatch, C ABI) and the per-polynomial-size
+// translation units of the K4 scan kernels (music_scan_inst.hip compiled once per compiled size, so the
+// ~250 kernel instantiations build in parallel).
+#pragma once
+#include "kernels.hpp"
+
+namespace doa {
+
+struct ScanPeakArgs {           // optional fused K5
+    const float *xaxis = nullptr;
+    float *val = nullptr, *loc = nullptr;
+    int M = 0;
+};
+
+// returns true when the fused peak pick ran (fast paths only)
+template <int N> bool launch_scan_n(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec,
+                                    void *d_q, const ScanPeakArgs &pk, hipStream_t st);
+
+#define DOA_SCAN_SIZES(X) X(2) X(3) X(4) X(6) X(8) X(12) X(16)
+#define DOA_SCAN_EXTERN(n)                                                                                         \
+    extern template bool launch_scan_n<n>(const MusicTables &, int, int, const void *, void *, void *,             \
+                                          const ScanPeakArgs &, hipStream_t);
+
+}  // namespace doa

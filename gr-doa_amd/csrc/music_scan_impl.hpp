@@ -1,0 +1,423 @@
+// music_scan_impl.hpp — K4 (spectrum scan, optionally with K5 fused) kernels and their launcher for one
+// compiled polynomial size; included only by music_scan_inst.hip.
+#pragma once
+#include "music_scan.hpp"
+#include "peak_device.hpp"
+
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+namespace doa {
+
+// ---------------------------------------------------------------------------------------------
+// K4: spectrum scan
+// ---------------------------------------------------------------------------------------------
+// Q = u0 + 2 Re( sum_{l=1}^{N-1} u_l z^l ) by Horner, in T (float or double).  c = the item's
+// coefficient record [u0, Re u1, Im u1, ...].
+template <int N, typename T> __device__ __forceinline__ T null_spectrum(const T (&c)[2 * N], T zr, T zi)
+{
+    if constexpr (N == 1) return c[0];
+    T hr = c[2 * (N - 1) - 1], hi = c[2 * (N - 1)];
+#pragma unroll
+    for (int l = N - 2; l >= 1; l--) {
+        const T tr = fma(hr, zr, fma(-hi, zi, c[2 * l - 1]));
+        const T ti = fma(hr, zi, fma(hi, zr, c[2 * l]));
+        hr = tr; hi = ti;
+    }
+    const T re = fma(hr, zr, -hi * zi);
+    return fma((T)2, re, c[0]);
+}
+
+__device__ __forceinline__ float db_from_ratio(float out, float mx, float inv_mx)
+{
+    // 10*log10(out/max).  The maximum itself must come out as exactly 0 dB (x/x == 1 in the
+    // reference; inf/inf stays NaN as there), everything else is out*(1/max) through the hardware
+    // log2: 10*log10(r) = (10*log10(2)) * log2(r).
+    // out <= max, so out/max <= 1 in the reference; the reciprocal multiply is clamped to keep that
+    float ratio = (out == mx && mx != INFINITY) ? 1.0f : fminf(out * inv_mx, 1.0f);
+    return 3.0102999566398120f * __log2f(ratio);
+}
+
+// Fast path: P % 4 == 0 and P <= 256*CH.  One wave per item, grid-stride over items so that the
+// z table (4*CH angles per lane) is loaded once per wave and stays in registers.  With PEAK the
+// find_local_max step (K5) runs on the dB values while they are still in registers, so the spectrum
+// is written once and never read back.
+template <int N, int CH, typename T, bool HAS_Q, bool PEAK, bool NT = false, bool ZREG = true>
+__global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
+                                                         float *__restrict__ spec, float *__restrict__ qout, int P,
+                                                         int n_items, const float *__restrict__ xaxis,
+                                                         float *__restrict__ pk_val, float *__restrict__ pk_loc, int M,
+                                                         int n_ant)
+{
+    // N is the compiled polynomial size (>= n_ant, the array's element count): records are 2*n_ant
+    // values long and the missing high-order coefficients are zero, which leaves Q unchanged
+    const int rec = 2 * n_ant;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
+    const int n_waves = gridDim.x * (blockDim.x / kWave);
+
+    // the x axis of the fused peak pick lives in LDS: the arg-max -> location lookup at the end of
+    // every item is then a ~100-cycle ds_read instead of a dependent global load the wave has to
+    // sit out (measured: 30 % of the wave's cycles were spent in that wait)
+    __shared__ float xs[PEAK ? 256 * CH : 1];
+    if constexpr (PEAK) {
+        for (int i = threadIdx.x; i < 256 * CH; i += blockDim.x) xs[i] = (i < P) ? xaxis[i] : 0.f;
+        __syncthreads();
+    }
+    // ZREG: the z table of this lane's 4*CH angles stays in registers across items.  Long spectra in
+    // double (CH > 4: more than 128 VGPRs of table) re-read it from L2 per item instead, which is
+    // noise next to their (N-1)-step double Horner.
+    constexpr int ZCH = ZREG ? CH : 1;
+    T zr[ZCH][4], zi[ZCH][4];
+    if constexpr (ZREG) {
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const int i0 = 4 * lane + 256 * j;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (i0 < P) { zr[j][e] = ztab[2 * (i0 + e)]; zi[j][e] = ztab[2 * (i0 + e) + 1]; }
+                else { zr[j][e] = 1; zi[j][e] = 0; }
+            }
+        }
+    }
+    // coefficient records arrive through scalar loads (wave-uniform address); the next item's record
+    // is requested before this item's arithmetic so its latency hides behind it
+    T c[2 * N], c_next[2 * N];
+    if (wave < n_items) {
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) c_next[k] = (k < rec - 1) ? coef[(size_t)wave * rec + k] : (T)0;
+    }
+    // One item: Q at this lane's 4*CH angles, 1/Q, wave maximum, dB, stores, optional peak pick.
+    // FULL (P == 256*CH, the usual power-of-two lengths) drops every bounds predicate.
+    auto do_item = [&](int item, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        float out[CH][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const bool live = FULL || ((4 * lane + 256 * j) < P);
+            if constexpr (!ZREG) {
+                const int i0 = 4 * lane + 256 * j;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (live) { zr[0][e] = ztab[2 * (i0 + e)]; zi[0][e] = ztab[2 * (i0 + e) + 1]; }
+                    else { zr[0][e] = 1; zi[0][e] = 0; }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float q = (float)null_spectrum<N, T>(c, zr[ZREG ? j : 0][e], zi[ZREG ? j : 0][e]);
+                if constexpr (HAS_Q) {
+                    if (live) qout[(size_t)item * P + 4 * lane + 256 * j + e] = q;
+                }
+                out[j][e] = __builtin_amdgcn_rcpf(q);           // 1.0/Q  (:140)
+                mx = live ? fmaxf(mx, out[j][e]) : mx;
+            }
+        }
+        mx = wave_allreduce_max(mx);
+        float *row = spec + (size_t)item * P;
+        // common case, wave-uniform: a finite positive maximum.  Then every ratio out/max is <= 1, the
+        // maximum maps to exactly 0 dB, and for num_max_vals == 1 the arg-max (arma index_max: first
+        // occurrence of the largest value, NaNs never win) is simply the first position whose dB is 0.
+        const bool regular = (mx > 0.0f) && (mx < INFINITY);
+        if (regular) {
+            const float inv_mx = __builtin_amdgcn_rcpf(mx);
+            int first_zero = INT_MAX;
+#pragma unroll
+            for (int j = CH - 1; j >= 0; j--) {
+                const int i0 = 4 * lane + 256 * j;
+#pragma unroll
+                for (int e = 3; e >= 0; e--) {
+                    const float o = out[j][e];
+                    const float ratio = (o == mx) ? 1.0f : fminf(o * inv_mx, 1.0f);
+                    const float db = 3.0102999566398120f * __log2f(ratio);       // 10*log10(ratio)
+                    out[j][e] = db;
+                    if constexpr (PEAK) {
+                        if (FULL || i0 < P) first_zero = (db == 0.0f) ? (i0 + e) : first_zero;
+                    }
+                }
+                if (FULL || i0 < P)
+                    store_f4<NT>(reinterpret_cast<float4 *>(row + i0), make_float4(out[j][0], out[j][1], out[j][2], out[j][3]));
+            }
+            if constexpr (PEAK) {
+                if (M == 1) {
+                    const int pos = wave_allreduce_min_int(first_zero);
+                    if (lane == 0) {
+                        pk_val[(size_t)item] = 0.0f;                 // the maximum is exactly 0 dB
+                        pk_loc[(size_t)item] = xs[pos];
+                    }
+                    return;
+                }
+            }
+        } else {
+            const float inv_mx = __builtin_amdgcn_rcpf(mx);
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const int i0 = 4 * lane + 256 * j;
+#pragma unroll
+                for (int e = 0; e < 4; e++) out[j][e] = db_from_ratio(out[j][e], mx, inv_mx);
+                if (FULL || i0 < P)
+                    store_f4<NT>(reinterpret_cast<float4 *>(row + i0), make_float4(out[j][0], out[j][1], out[j][2], out[j][3]));
+            }
+        }
+        if constexpr (PEAK) peak_pick<CH>(out, lane, P, M, xs, pk_val + (size_t)item * M, pk_loc + (size_t)item * M);
+    };
+    const bool full = (P == 256 * CH);
+    for (int item = wave; item < n_items; item += n_waves) {
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) c[k] = c_next[k];
+        const int nxt = item + n_waves;
+        if (nxt < n_items) {
+#pragma unroll
+            for (int k = 0; k < 2 * N; k++) c_next[k] = (k < rec - 1) ? coef[(size_t)nxt * rec + k] : (T)0;
+        }
+        if (full) do_item(item, std::true_type{});
+        else do_item(item, std::false_type{});
+    }
+}
+
+// N <= 4 in double: Q(psi) = u0 + 2 sum_l (a_l cos(l psi) - b_l sin(l psi)), u_l = a_l + j b_l, rewritten
+// with cos 2x = 2c^2-1, cos 3x = 4c^3-3c, sin 2x = 2sc, sin 3x = s(4c^2-1) (c = cos psi, s = sin psi) as
+//     Q = A(c) + s B(c),   A = (u0-2a2) + (2a1-6a3) c + 4a2 c^2 + 8a3 c^3,   B = (2b3-2b1) - 4b2 c - 8b3 c^2
+// : 6 fused multiply-adds per angle instead of the 11 of the complex Horner form (the per-item
+// coefficient transform is wave-uniform).  Degree 3 keeps the Chebyshev -> monomial change of basis
+// harmless (|coefficients| grow by <= 8); it is used for the double path only, where its rounding
+// (~1e-15 of the largest term) is far below the 1e-7 the float output resolves.
+template <int N, typename T> struct ChebQ {
+    T a0, a1, a2, a3, b0, b1, b2;
+    __device__ __forceinline__ explicit ChebQ(const T (&c)[2 * N])
+    {
+        const T u0 = c[0];
+        const T x1 = (N > 1) ? c[1] : (T)0, y1 = (N > 1) ? c[2] : (T)0;
+        const T x2 = (N > 2) ? c[3] : (T)0, y2 = (N > 2) ? c[4] : (T)0;
+        const T x3 = (N > 3) ? c[5] : (T)0, y3 = (N > 3) ? c[6] : (T)0;
+        a0 = u0 - 2 * x2; a1 = 2 * x1 - 6 * x3; a2 = 4 * x2; a3 = 8 * x3;
+        b0 = 2 * y3 - 2 * y1; b1 = -4 * y2; b2 = -8 * y3;
+    }
+    __device__ __forceinline__ T operator()(T cs, T sn) const
+    {
+        const T A = fma(fma(fma(a3, cs, a2), cs, a1), cs, a0);
+        const T B = fma(fma(b2, cs, b1), cs, b0);
+        return fma(sn, B, A);
+    }
+};
+
+// The benchmark shape of K4+K5 as its own lean kernel: P == 256*CH exactly (no bounds predicates),
+// num_max_vals == 1 (the peak pick is "first position whose dB equals the maximum", a 6-step DPP
+// integer minimum), compiled polynomial size == the array size (unconditional scalar loads of the
+// coefficient record).  Nothing generic is compiled in, which keeps it at ~110 VGPRs (4 waves per
+// SIMD) where the general kernel needs 200+.  Items whose maximum of 1/Q is not a finite positive
+// number (a zero, negative or non-finite null spectrum: non-finite input, in practice) take a slow
+// rolled path that follows the general kernel's semantics literally.
+template <int N, int CH, typename T>
+__global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
+                                                               float *__restrict__ spec, int n_items,
+                                                               const float *__restrict__ xaxis, float *__restrict__ pk_val,
+                                                               float *__restrict__ pk_loc)
+{
+    constexpr int P = 256 * CH;
+    __shared__ float xs[P];
+    for (int i = threadIdx.x; i < P; i += blockDim.x) xs[i] = xaxis[i];
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
+    const int n_waves = gridDim.x * (blockDim.x / kWave);
+    T zr[CH][4], zi[CH][4];
+#pragma unroll
+    for (int j = 0; j < CH; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = 4 * lane + 256 * j + e;
+            zr[j][e] = ztab[2 * i]; zi[j][e] = ztab[2 * i + 1];
+        }
+    T c[2 * N], c_next[2 * N];
+    if (wave < n_items) {
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) c_next[k] = coef[(size_t)wave * (2 * N) + k];
+    }
+    for (int item = wave; item < n_items; item += n_waves) {
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) c[k] = c_next[k];
+        const int nxt = item + n_waves;
+        if (nxt < n_items) {
+#pragma unroll
+            for (int k = 0; k < 2 * N; k++) c_next[k] = coef[(size_t)nxt * (2 * N) + k];
+        }
+        // pass 1: the null spectrum itself (no reciprocal) and its minimum over the item
+        float qf[CH][4];
+        float mn = INFINITY;
+        if constexpr (N <= 4 && sizeof(T) == 8) {
+            const ChebQ<N, T> Q(c);
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    qf[j][e] = (float)Q(zr[j][e], zi[j][e]);
+                    mn = fminf(mn, qf[j][e]);
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    qf[j][e] = (float)null_spectrum<N, T>(c, zr[j][e], zi[j][e]);
+                    mn = fminf(mn, qf[j][e]);
+                }
+        }
+        mn = wave_allreduce_min(mn);
+        float *row = spec + (size_t)item * P;
+        if ((mn > 0.0f) && (mn < INFINITY)) {
+            // pass 2: 10 log10((1/Q)/max(1/Q)) = -10 log10(2) * log2(Q/Qmin): one transcendental per angle.
+            // 1/Qmin is biased down by 2 ulp so that Qmin/Qmin <= 1 whatever v_rcp rounds to; t <= 1 is
+            // then "this angle holds the maximum" (0 dB exactly, as x/x == 1 in the reference), and the
+            // first such angle of the item is find_local_max's answer for num_max_vals == 1.  The compare
+            // lands in an SGPR pair, so the position search is scalar work beside the vector pipe.
+            const float inv_mn = __builtin_amdgcn_rcpf(mn) * 0.99999976158142f;
+            int pos = INT_MAX;
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                float db[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float t = qf[j][e] * inv_mn;
+                    const unsigned long long at_max = __builtin_amdgcn_ballot_w64(t <= 1.0f);
+                    const int cand = at_max ? (4 * (int)__builtin_ctzll(at_max) + 256 * j + e) : INT_MAX;
+                    pos = min(pos, cand);
+                    db[e] = fmaf(-3.0102999566398120f, __log2f(fmaxf(t, 1.0f)), 0.0f);     // +0.0 at the maximum
+                }
+                store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(db[0], db[1], db[2], db[3]));
+            }
+            if (lane == 0) { pk_val[item] = 0.0f; pk_loc[item] = xs[pos]; }
+        } else {
+            // rare: follow the general semantics (db_from_ratio, arma index_max) without unrolling
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_amdgcn_rcpf(qf[j][e]));
+            mx = wave_allreduce_max(mx);
+            const float inv_mx = __builtin_amdgcn_rcpf(mx);
+            float bv = 0.f;
+            int bi = INT_MAX;
+            float v0 = 0.f;
+#pragma unroll 1
+            for (int j = 0; j < CH; j++)
+#pragma unroll 1
+                for (int e = 0; e < 4; e++) {
+                    const int i = 4 * lane + 256 * j + e;
+                    const float o = __builtin_amdgcn_rcpf((float)null_spectrum<N, T>(c, (T)ztab[2 * i], (T)ztab[2 * i + 1]));
+                    const float db = db_from_ratio(o, mx, inv_mx);
+                    row[i] = db;
+                    if (i == 0) v0 = db;
+                    if (db > -INFINITY && cand_better(db, i, bv, bi)) { bv = db; bi = i; }
+                }
+            wave_argbest(bv, bi);
+            v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), 0));
+            if (lane == 0) {
+                pk_val[item] = (bi == INT_MAX) ? v0 : bv;
+                pk_loc[item] = xs[(bi == INT_MAX) ? 0 : bi];
+            }
+        }
+    }
+}
+
+// Any P: one wave per item, one angle per lane per step, two passes (max, then write).
+template <int N, typename T>
+__global__ __launch_bounds__(256) void music_scan_generic_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
+                                                                 float *__restrict__ spec, float *__restrict__ qout, int P,
+                                                                 int n_items, int n_ant)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
+    const int n_waves = gridDim.x * (blockDim.x / kWave);
+    const int rec = 2 * n_ant;
+    for (int item = wave; item < n_items; item += n_waves) {
+        const T *co = coef + (size_t)item * rec;
+        T c[2 * N];
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) c[k] = (k < rec - 1) ? co[k] : (T)0;
+        float mx = -INFINITY;
+        for (int i = lane; i < P; i += kWave) {
+            const float q = (float)null_spectrum<N, T>(c, ztab[2 * i], ztab[2 * i + 1]);
+            if (qout) qout[(size_t)item * P + i] = q;
+            mx = fmaxf(mx, __builtin_amdgcn_rcpf(q));
+        }
+        mx = wave_allreduce_max(mx);
+        const float inv_mx = __builtin_amdgcn_rcpf(mx);
+        for (int i = lane; i < P; i += kWave) {
+            const float o = __builtin_amdgcn_rcpf((float)null_spectrum<N, T>(c, ztab[2 * i], ztab[2 * i + 1]));
+            spec[(size_t)item * P + i] = db_from_ratio(o, mx, inv_mx);
+        }
+    }
+}
+
+
+template <int N, int CH, typename T, bool ZREG = true>
+static void launch_scan_fast(dim3 grid, dim3 block, hipStream_t st, const T *co, const T *z, float *sp, float *q, int P,
+                             int n_items, const ScanPeakArgs &pk, int n_ant)
+{
+    // three variants: diagnostics (Q out), plain, fused with the peak pick; spectra are write-once ->
+    // non-temporal stores in the two production variants
+    if (q)
+        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, true, false, false, ZREG>), grid, block, 0, st, co, z, sp, q, P,
+                           n_items, nullptr, nullptr, nullptr, 0, n_ant);
+    else if (pk.val)
+        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, true, true, ZREG>), grid, block, 0, st, co, z, sp, q, P,
+                           n_items, pk.xaxis, pk.val, pk.loc, pk.M, n_ant);
+    else
+        hipLaunchKernelGGL((music_scan_kernel<N, CH, T, false, false, true, ZREG>), grid, block, 0, st, co, z, sp, q, P,
+                           n_items, nullptr, nullptr, nullptr, 0, n_ant);
+}
+
+// returns true when the fused peak pick ran (fast path only)
+template <int N, typename T>
+static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_spec, void *d_q, const ScanPeakArgs &pk,
+                           int n_ant, hipStream_t st)
+{
+    float *sp = (float *)d_spec, *q = (float *)d_q;
+    const int waves_per_block = 4;
+    const bool aligned = (P % 4 == 0) && (reinterpret_cast<uintptr_t>(d_spec) % 16 == 0);
+    // two items per wave at the benchmark batch: the z table is loaded once per wave and the next
+    // item's coefficient record is prefetched behind the current item's arithmetic
+    int blocks = (n_items + waves_per_block - 1) / waves_per_block;
+    static const int wpc = [] { const char *e = getenv("DOA_SCAN_WAVES_PER_CU"); return e ? atoi(e) : 8; }();
+    const int max_blocks = 256 * wpc / waves_per_block;
+    if (blocks > max_blocks) blocks = max_blocks;
+    dim3 grid(blocks), block(waves_per_block * kWave);
+    // the lean benchmark-shape kernel (see music_scan_peak1_kernel)
+    static const int lean = [] { const char *e = getenv("DOA_SCAN_LEAN"); return e ? atoi(e) : 1; }();
+    if (lean && aligned && pk.val && pk.M == 1 && !q && n_ant == N && (P == 256 || P == 512 || P == 1024)) {
+        int lb = (n_items + waves_per_block - 1) / waves_per_block;
+        static const int lwpc = [] { const char *e = getenv("DOA_SCAN_LEAN_WAVES_PER_CU"); return e ? atoi(e) : 8; }();
+        if (lb > 256 * lwpc / waves_per_block) lb = 256 * lwpc / waves_per_block;
+        dim3 lgrid(lb);
+        if (P == 256) hipLaunchKernelGGL((music_scan_peak1_kernel<N, 1, T>), lgrid, block, 0, st, co, z, sp, n_items, pk.xaxis, pk.val, pk.loc);
+        else if (P == 512) hipLaunchKernelGGL((music_scan_peak1_kernel<N, 2, T>), lgrid, block, 0, st, co, z, sp, n_items, pk.xaxis, pk.val, pk.loc);
+        else hipLaunchKernelGGL((music_scan_peak1_kernel<N, 4, T>), lgrid, block, 0, st, co, z, sp, n_items, pk.xaxis, pk.val, pk.loc);
+        return true;
+    }
+    if (aligned && P <= 4096) {
+        constexpr bool ZBIG = (sizeof(T) == 4);          // float tables fit the register file up to P = 4096
+        if (P <= 256) launch_scan_fast<N, 1, T>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
+        else if (P <= 512) launch_scan_fast<N, 2, T>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
+        else if (P <= 1024) launch_scan_fast<N, 4, T>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
+        else if (P <= 2048) launch_scan_fast<N, 8, T, ZBIG>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
+        else launch_scan_fast<N, 16, T, ZBIG>(grid, block, st, co, z, sp, q, P, n_items, pk, n_ant);
+        return pk.val != nullptr && q == nullptr;
+    }
+    hipLaunchKernelGGL((music_scan_generic_kernel<N, T>), grid, block, 0, st, co, z, sp, q, P, n_items, n_ant);
+    return false;
+}
+
+template <int N> bool launch_scan_n(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec,
+                                           void *d_q, const ScanPeakArgs &pk, hipStream_t st)
+{
+    if (bits == 32)
+        return launch_scan_nt<N, float>((const float *)d_coef, t.d_z.as<float>(), t.P, n_items, d_spec, d_q, pk, t.N, st);
+    return launch_scan_nt<N, double>((const double *)d_coef, t.d_zd.as<double>(), t.P, n_items, d_spec, d_q, pk, t.N, st);
+}
+
+
+}  // namespace doa
