@@ -21,6 +21,9 @@
 
 namespace doa {
 
+// |p(z)| <= kResidualFloor * (degree+1) * sum |c_m||z|^m counts as "zero to working precision" (16 eps)
+constexpr double kResidualFloor = 16.0 * 2.220446049250313e-16;
+
 template <int N, bool UNROLL>
 __device__ __forceinline__ void aberth_roots(const double (&cr)[2 * N - 1], const double (&ci)[2 * N - 1],
                                              double (&zr)[2 * N - 2], double (&zi)[2 * N - 2])
@@ -43,6 +46,9 @@ __device__ __forceinline__ void aberth_roots(const double (&cr)[2 * N - 1], cons
         for (int k = 0; k < D; k++) {
             // Horner for p and p' at z_k
             double pr = cr[D], pi = ci[D], dr = 0.0, di = 0.0;
+            // running bound of the rounding error of p(z_k): sum |c_m| |z_k|^m (|c_m| taken as |re|+|im|)
+            const double rk = (double)sqrtf((float)(zr[k] * zr[k] + zi[k] * zi[k]));
+            double eb = fabs(cr[D]) + fabs(ci[D]);
 #pragma unroll U
             for (int m = D - 1; m >= 0; m--) {
                 const double ndr = dr * zr[k] - di * zi[k] + pr;
@@ -51,7 +57,13 @@ __device__ __forceinline__ void aberth_roots(const double (&cr)[2 * N - 1], cons
                 const double npr = pr * zr[k] - pi * zi[k] + cr[m];
                 const double npi = pr * zi[k] + pi * zr[k] + ci[m];
                 pr = npr; pi = npi;
+                eb = fma(eb, rk, fabs(cr[m]) + fabs(ci[m]));
             }
+            // |p(z_k)| at its rounding floor: the root is as good as double Horner can tell (Root-MUSIC's
+            // pairs z, 1/conj(z) sit 1e-3..1e-5 apart, so the step itself never falls to 1e-15 relative:
+            // without this test such items ran to the iteration cap)
+            const double floor_k = kResidualFloor * (D + 1) * eb;
+            if (pr * pr + pi * pi <= floor_k * floor_k) continue;
             // w = p/p'
             const double dn = dr * dr + di * di;
             double wr, wi;
@@ -155,7 +167,21 @@ template <int GR> __device__ __forceinline__ double group_max_d(double v, int la
     return v;
 }
 
-template <int GR>
+// 1/x for a finite positive double well inside the exponent range: hardware seed + two Newton steps
+// (what the compiler's IEEE division expands to, minus its scaling / fix-up instructions: ~6 instead
+// of ~18 instructions, and one reciprocal serves both parts of a complex quotient)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+
+// DEG = compile-time polynomial degree when it is known to be below GR (N = 4: degree 6 on 8 lanes),
+// so that neither the Horner recurrence nor the root-pair loop spends steps on padding.
+template <int GR, int DEG = GR>
 __global__ __launch_bounds__(64) void root_music_group_kernel(const double *__restrict__ coef, float *__restrict__ out,
                                                               int *__restrict__ status, int n_items, int N, int M,
                                                               double two_pi_d)
@@ -170,7 +196,7 @@ __global__ __launch_bounds__(64) void root_music_group_kernel(const double *__re
     const bool is_root = k < D;
     const double *co = coef + (size_t)item * (2 * N);
     // polynomial c[m], m = 0..D: c[N-1-l] = u_l, c[N-1+l] = conj(u_l); zero above D
-    double cr[GR + 1], ci[GR + 1];
+    double cr[GR + 1], ci[GR + 1], ca[GR + 1];
 #pragma unroll
     for (int m = 0; m <= GR; m++) {
         double vr = 0.0, vi = 0.0;
@@ -179,7 +205,7 @@ __global__ __launch_bounds__(64) void root_music_group_kernel(const double *__re
             if (l == 0) vr = co[0];
             else { vr = co[2 * l - 1]; vi = (m < N - 1) ? co[2 * l] : -co[2 * l]; }
         }
-        cr[m] = vr; ci[m] = vi;
+        cr[m] = vr; ci[m] = vi; ca[m] = fabs(vr) + fabs(vi);
     }
     double zr, zi;
     {
@@ -190,40 +216,43 @@ __global__ __launch_bounds__(64) void root_music_group_kernel(const double *__re
         zr = is_root ? rad * cs : 1e6 * (k + 1);          // idle lanes park far away and never move
         zi = is_root ? rad * sn : 0.0;
     }
-    for (int it = 0; it < 160; it++) {
-        double pr = 0.0, pi = 0.0, dr = 0.0, di = 0.0;
+    for (int it = 0; it < 80; it++) {
+        double pr = 0.0, pi = 0.0, dr = 0.0, di = 0.0, eb = 0.0;
+        const double rk = (double)sqrtf((float)(zr * zr + zi * zi));
 #pragma unroll
-        for (int m = GR; m >= 0; m--) {
+        for (int m = DEG; m >= 0; m--) {
             const double ndr = dr * zr - di * zi + pr;
             const double ndi = dr * zi + di * zr + pi;
             dr = ndr; di = ndi;
             const double npr = pr * zr - pi * zi + cr[m];
             const double npi = pr * zi + pi * zr + ci[m];
             pr = npr; pi = npi;
+            eb = fma(eb, rk, ca[m]);             // rounding-error bound of p(z): sum |c_m| |z|^m
         }
-        // (coefficients above degree D are zero, so starting the recurrence at GR changes nothing)
+        const double floor_k = kResidualFloor * (D + 1) * eb;
+        const bool at_floor = (pr * pr + pi * pi <= floor_k * floor_k);   // see aberth_roots
+        // (coefficients above degree D are zero, so starting the recurrence at DEG >= D changes nothing)
         const double dn = dr * dr + di * di;
         double wr = 1e-3, wi = 1e-3;
-        if (dn > 0.0) { wr = (pr * dr + pi * di) / dn; wi = (pi * dr - pr * di) / dn; }
+        if (dn > 0.0) { const double inv = fast_rcp(dn); wr = (pr * dr + pi * di) * inv; wi = (pi * dr - pr * di) * inv; }
         double sr = 0.0, si = 0.0;
 #pragma unroll
-        for (int j = 0; j < GR; j++) {
+        for (int j = 0; j < DEG; j++) {
             const double ojr = __shfl(zr, base + j, kWave), oji = __shfl(zi, base + j, kWave);
             const double er = zr - ojr, ei = zi - oji;
             const double en = er * er + ei * ei;
-            if (j != k && j < D && en > 0.0) { sr += er / en; si -= ei / en; }
+            if (j != k && j < D && en > 0.0) { const double inv = fast_rcp(en); sr = fma(er, inv, sr); si = fma(-ei, inv, si); }
         }
         const double qr = 1.0 - (wr * sr - wi * si), qi = -(wr * si + wi * sr);
         const double qn = qr * qr + qi * qi;
         double er = wr, ei = wi;
-        if (qn > 0.0) { er = (wr * qr + wi * qi) / qn; ei = (wi * qr - wr * qi) / qn; }
+        if (qn > 0.0) { const double inv = fast_rcp(qn); er = (wr * qr + wi * qi) * inv; ei = (wi * qr - wr * qi) * inv; }
         double rel = 0.0;
-        if (is_root) {
+        if (is_root && !at_floor) {
             zr -= er; zi -= ei;
             rel = (er * er + ei * ei) / (1.0 + zr * zr + zi * zi);
         }
-        const double worst = group_max_d<GR>(rel, lane);
-        if (!__any(worst >= 1e-29)) break;          // every group of the wave has converged
+        if (__ballot(rel >= 1e-29) == 0ull) break;   // every root of every group of the wave has converged
     }
     // dist = 1 - |z|; keep dist > 0; the M smallest, one at a time (:122-141)
     double dist = is_root ? 1.0 - sqrt(zr * zr + zi * zi) : -1.0;
@@ -269,13 +298,13 @@ __global__ __launch_bounds__(64) void root_music_group_kernel(const double *__re
     }
 }
 
-template <int GR>
+template <int GR, int DEG = GR>
 static void launch_root_group(int N, int M, int n_items, const void *d_coef, void *d_out, void *d_status, double two_pi_d,
                               hipStream_t st)
 {
     constexpr int IPW = kWave / GR;
     dim3 block(64), grid((n_items + IPW - 1) / IPW);
-    hipLaunchKernelGGL(root_music_group_kernel<GR>, grid, block, 0, st, (const double *)d_coef, (float *)d_out,
+    hipLaunchKernelGGL((root_music_group_kernel<GR, DEG>), grid, block, 0, st, (const double *)d_coef, (float *)d_out,
                        (int *)d_status, n_items, N, M, two_pi_d);
 }
 
@@ -293,6 +322,7 @@ int launch_root_music(int N, int M, float norm_spacing, int n_items, const void 
         const int D = 2 * N - 2;
         if (D <= 2) launch_root_group<2>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
         else if (D <= 4) launch_root_group<4>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
+        else if (D == 6) launch_root_group<8, 6>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
         else if (D <= 8) launch_root_group<8>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
         else if (D <= 16) launch_root_group<16>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
         else launch_root_group<32>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);

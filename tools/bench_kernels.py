@@ -24,8 +24,12 @@ doa.set_internal_precision(args.precision)
 st = torch.cuda.current_stream()
 streams = []
 for b in range(args.nbuf):
-    x = torch.randn((N, B * K, 2), device="cuda", dtype=torch.float32)
-    streams.append([torch.view_as_complex(x[n].contiguous()) for n in range(N)])
+    if os.environ.get("BENCH_NOISE_ONLY"):       # pure noise: the worst case for the iterative kernels
+        x = torch.randn((N, B * K, 2), device="cuda", dtype=torch.float32)
+        streams.append([torch.view_as_complex(x[n].contiguous()) for n in range(N)])
+    else:                                        # M sources at SNR 20 dB, a random direction set per snapshot
+        s_, _ = doa.sim.make_batch_streams_torch(N, K, B, 0.5, M, 20.0, seed=b)
+        streams.append(s_)
 ptrs = [[t.data_ptr() for t in s] for s in streams]
 cov = [torch.empty((B, N * N), dtype=torch.complex64, device="cuda") for _ in range(args.nbuf)]
 spec = [torch.empty((B, P), dtype=torch.float32, device="cuda") for _ in range(args.nbuf)]
