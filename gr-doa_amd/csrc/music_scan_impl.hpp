@@ -211,11 +211,13 @@ template <int N, typename T> struct ChebQ {
 // SIMD) where the general kernel needs 200+.  Items whose maximum of 1/Q is not a finite positive
 // number (a zero, negative or non-finite null spectrum: non-finite input, in practice) take a slow
 // rolled path that follows the general kernel's semantics literally.
-template <int N, int CH, typename T>
+// MULTI: num_max_vals > 1 (the flowgraph's two sources): same arithmetic, the dB values stay in
+// registers and go through the general peak_pick.
+template <int N, int CH, typename T, bool MULTI = false>
 __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                                float *__restrict__ spec, int n_items,
                                                                const float *__restrict__ xaxis, float *__restrict__ pk_val,
-                                                               float *__restrict__ pk_loc)
+                                                               float *__restrict__ pk_loc, int M)
 {
     constexpr int P = 256 * CH;
     __shared__ float xs[P];
@@ -275,21 +277,33 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
             // first such angle of the item is find_local_max's answer for num_max_vals == 1.  The compare
             // lands in an SGPR pair, so the position search is scalar work beside the vector pipe.
             const float inv_mn = __builtin_amdgcn_rcpf(mn) * 0.99999976158142f;
-            int pos = INT_MAX;
+            if constexpr (MULTI) {
 #pragma unroll
-            for (int j = 0; j < CH; j++) {
-                float db[4];
+                for (int j = 0; j < CH; j++) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float t = qf[j][e] * inv_mn;
-                    const unsigned long long at_max = __builtin_amdgcn_ballot_w64(t <= 1.0f);
-                    const int cand = at_max ? (4 * (int)__builtin_ctzll(at_max) + 256 * j + e) : INT_MAX;
-                    pos = min(pos, cand);
-                    db[e] = fmaf(-3.0102999566398120f, __log2f(fmaxf(t, 1.0f)), 0.0f);     // +0.0 at the maximum
+                    for (int e = 0; e < 4; e++)
+                        qf[j][e] = fmaf(-3.0102999566398120f, __log2f(fmaxf(qf[j][e] * inv_mn, 1.0f)), 0.0f);
+                    store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
+                                   make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
                 }
-                store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(db[0], db[1], db[2], db[3]));
+                peak_pick<CH>(qf, lane, P, M, xs, pk_val + (size_t)item * M, pk_loc + (size_t)item * M);
+            } else {
+                int pos = INT_MAX;
+#pragma unroll
+                for (int j = 0; j < CH; j++) {
+                    float db[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float t = qf[j][e] * inv_mn;
+                        const unsigned long long at_max = __builtin_amdgcn_ballot_w64(t <= 1.0f);
+                        const int cand = at_max ? (4 * (int)__builtin_ctzll(at_max) + 256 * j + e) : INT_MAX;
+                        pos = min(pos, cand);
+                        db[e] = fmaf(-3.0102999566398120f, __log2f(fmaxf(t, 1.0f)), 0.0f);     // +0.0 at the maximum
+                    }
+                    store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(db[0], db[1], db[2], db[3]));
+                }
+                if (lane == 0) { pk_val[item] = 0.0f; pk_loc[item] = xs[pos]; }
             }
-            if (lane == 0) { pk_val[item] = 0.0f; pk_loc[item] = xs[pos]; }
         } else {
             // rare: follow the general semantics (db_from_ratio, arma index_max) without unrolling
             float mx = -INFINITY;
@@ -299,6 +313,17 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
                 for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_amdgcn_rcpf(qf[j][e]));
             mx = wave_allreduce_max(mx);
             const float inv_mx = __builtin_amdgcn_rcpf(mx);
+            if constexpr (MULTI) {
+#pragma unroll
+                for (int j = 0; j < CH; j++) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) qf[j][e] = db_from_ratio(__builtin_amdgcn_rcpf(qf[j][e]), mx, inv_mx);
+                    store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
+                                   make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
+                }
+                peak_pick<CH>(qf, lane, P, M, xs, pk_val + (size_t)item * M, pk_loc + (size_t)item * M);
+                continue;
+            }
             float bv = 0.f;
             int bi = INT_MAX;
             float v0 = 0.f;
@@ -388,14 +413,24 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
     dim3 grid(blocks), block(waves_per_block * kWave);
     // the lean benchmark-shape kernel (see music_scan_peak1_kernel)
     static const int lean = [] { const char *e = getenv("DOA_SCAN_LEAN"); return e ? atoi(e) : 1; }();
-    if (lean && aligned && pk.val && pk.M == 1 && !q && n_ant == N && (P == 256 || P == 512 || P == 1024)) {
+    if (lean && aligned && pk.val && pk.M >= 1 && !q && n_ant == N && (P == 256 || P == 512 || P == 1024)) {
         int lb = (n_items + waves_per_block - 1) / waves_per_block;
         static const int lwpc = [] { const char *e = getenv("DOA_SCAN_LEAN_WAVES_PER_CU"); return e ? atoi(e) : 8; }();
         if (lb > 256 * lwpc / waves_per_block) lb = 256 * lwpc / waves_per_block;
         dim3 lgrid(lb);
-        if (P == 256) hipLaunchKernelGGL((music_scan_peak1_kernel<N, 1, T>), lgrid, block, 0, st, co, z, sp, n_items, pk.xaxis, pk.val, pk.loc);
-        else if (P == 512) hipLaunchKernelGGL((music_scan_peak1_kernel<N, 2, T>), lgrid, block, 0, st, co, z, sp, n_items, pk.xaxis, pk.val, pk.loc);
-        else hipLaunchKernelGGL((music_scan_peak1_kernel<N, 4, T>), lgrid, block, 0, st, co, z, sp, n_items, pk.xaxis, pk.val, pk.loc);
+#define DOA_LEAN_LAUNCH(CH_, MULTI_)                                                                              \
+    hipLaunchKernelGGL((music_scan_peak1_kernel<N, CH_, T, MULTI_>), lgrid, block, 0, st, co, z, sp, n_items, pk.xaxis, \
+                       pk.val, pk.loc, pk.M)
+        if (pk.M == 1) {
+            if (P == 256) DOA_LEAN_LAUNCH(1, false);
+            else if (P == 512) DOA_LEAN_LAUNCH(2, false);
+            else DOA_LEAN_LAUNCH(4, false);
+        } else {
+            if (P == 256) DOA_LEAN_LAUNCH(1, true);
+            else if (P == 512) DOA_LEAN_LAUNCH(2, true);
+            else DOA_LEAN_LAUNCH(4, true);
+        }
+#undef DOA_LEAN_LAUNCH
         return true;
     }
     if (aligned && P <= 4096) {
