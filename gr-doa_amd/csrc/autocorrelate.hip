@@ -29,6 +29,10 @@ struct CovArgs {
     float inv_k;   // (float)(1.0/K)
     float fb_hk;   // (float)(0.5/K)
     const float2 *gain;   // optional [N*N] g_a conj(g_b) (fused antenna_correction), or nullptr
+    // read-once path for overlapping windows (cov_piece_kernel + cov_combine_kernel)
+    float2 *pieces;       // [n_steps][2][N*N] raw sums of the pieces A_j, B_j
+    int q, r;             // K = q*S + r
+    int n_steps;          // n_out + q
 };
 
 template <int TN> struct TriAcc {
@@ -162,6 +166,141 @@ __global__ __launch_bounds__(256) void cov_wave_kernel(CovArgs g)
     }  // snapshot loop
 }
 
+// ---------------------------------------------------------------------------------------------
+// Overlapping windows, read-once.  With S = K - overlap and K = q S + r, cut every stream at j S and
+// j S + r: step j owns piece A_j = [j S, j S + r) and piece B_j = [j S + r, (j+1) S), and
+//     window i  =  sum_{j=i}^{i+q-1} (A_j + B_j)  +  A_{i+q}.
+// cov_piece_kernel: one wave per step streams its S new samples ONCE (same loads, accumulators and DPP
+// reduction as cov_wave_kernel) and writes the two raw N x N piece sums (2 x 8N^2 B per step);
+// cov_combine_kernel adds the q+... pieces of each window and applies 1/K, the fused antenna
+// correction and the forward-backward step.  HBM traffic = the new samples only (the single-kernel
+// path re-fetches the overlap of almost every window: measured 253 MB against 201 MB algorithmic at
+// K = 2048, overlap = 512), and the overlap's multiply-adds are not repeated either.  The price is
+// one more (tiny) launch, so windows without overlap stay on cov_wave_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int TN, int UN, bool NT>
+__device__ __forceinline__ void accumulate_pairs(TriAcc<TN> &acc, const CovArgs &g, size_t first, int npair, int lane)
+{
+    const float2 *const *in = g.in;
+    int p = lane;
+    for (; p + (UN - 1) * kWave < npair; p += UN * kWave) {
+        float4 v[UN][TN];
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+#pragma unroll
+            for (int a = 0; a < TN; a++)
+                v[u][a] = load_f4<NT>(reinterpret_cast<const float4 *>(in[a] + first + 2 * (size_t)(p + u * kWave)));
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            float2 x0[TN], x1[TN];
+#pragma unroll
+            for (int a = 0; a < TN; a++) { x0[a] = make_float2(v[u][a].x, v[u][a].y); x1[a] = make_float2(v[u][a].z, v[u][a].w); }
+            tri_accumulate<TN>(acc, x0);
+            tri_accumulate<TN>(acc, x1);
+        }
+    }
+    for (; p < npair; p += kWave) {
+        float4 v[TN];
+#pragma unroll
+        for (int a = 0; a < TN; a++) v[a] = load_f4<NT>(reinterpret_cast<const float4 *>(in[a] + first + 2 * (size_t)p));
+        float2 x0[TN], x1[TN];
+#pragma unroll
+        for (int a = 0; a < TN; a++) { x0[a] = make_float2(v[a].x, v[a].y); x1[a] = make_float2(v[a].z, v[a].w); }
+        tri_accumulate<TN>(acc, x0);
+        tri_accumulate<TN>(acc, x1);
+    }
+}
+
+template <int TN> __device__ __forceinline__ void tri_clear(TriAcc<TN> &acc)
+{
+#pragma unroll
+    for (int a = 0; a < TN; a++) acc.d[a] = 0.f;
+#pragma unroll
+    for (int i = 0; i < TN * (TN - 1) / 2; i++) { acc.re[i] = 0.f; acc.im[i] = 0.f; }
+}
+
+// wave all-reduce, then lane e = a + b*N holds the raw sum of x_a conj(x_b)
+template <int TN> __device__ __forceinline__ float2 tri_reduce_to_lane(TriAcc<TN> &acc, int lane)
+{
+#pragma unroll
+    for (int a = 0; a < TN; a++) acc.d[a] = wave_allreduce_sum(acc.d[a]);
+#pragma unroll
+    for (int i = 0; i < TN * (TN - 1) / 2; i++) {
+        acc.re[i] = wave_allreduce_sum(acc.re[i]);
+        acc.im[i] = wave_allreduce_sum(acc.im[i]);
+    }
+    float2 r = make_float2(0.f, 0.f);
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+        if (lane == a + a * TN) r = make_float2(acc.d[a], 0.f);
+#pragma unroll
+        for (int b = a + 1; b < TN; b++) {
+            if (lane == a + b * TN) r = make_float2(acc.re[idx], acc.im[idx]);
+            if (lane == b + a * TN) r = make_float2(acc.re[idx], -acc.im[idx]);
+            idx++;
+        }
+    }
+    return r;
+}
+
+// requires: S and r even, every stream base 16-B aligned (float4 loads at every piece start)
+template <int TN, int UN, bool NT>
+__global__ __launch_bounds__(256) void cov_piece_kernel(CovArgs g)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave0 = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const int n_waves = gridDim.x * (blockDim.x / kWave);
+    for (int step = wave0; step < g.n_steps; step += n_waves) {
+        const size_t base = (size_t)step * (size_t)g.S;
+        float2 *po = g.pieces + (size_t)step * (2 * TN * TN);
+        TriAcc<TN> acc;
+        if (g.r > 0) {                                     // piece A_j
+            tri_clear<TN>(acc);
+            accumulate_pairs<TN, UN, NT>(acc, g, base, g.r >> 1, lane);
+            const float2 v = tri_reduce_to_lane<TN>(acc, lane);
+            if (lane < TN * TN) po[lane] = v;
+        }
+        if (step + 1 < g.n_steps) {                        // piece B_j (the last step only contributes its A)
+            tri_clear<TN>(acc);
+            accumulate_pairs<TN, UN, NT>(acc, g, base + (size_t)g.r, (g.S - g.r) >> 1, lane);
+            const float2 v = tri_reduce_to_lane<TN>(acc, lane);
+            if (lane < TN * TN) po[TN * TN + lane] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cov_combine_kernel(CovArgs g)
+{
+    const int nn = g.n_ch * g.n_ch;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)g.n_out * nn) return;
+    const int i = (int)(idx / nn), e = (int)(idx % nn);
+    auto window_sum = [&](int el) {
+        float sx = 0.f, sy = 0.f;
+        for (int j = i; j < i + g.q; j++) {
+            const float2 *pj = g.pieces + (size_t)j * (2 * nn);
+            if (g.r > 0) { const float2 a = pj[el]; sx = __fadd_rn(sx, a.x); sy = __fadd_rn(sy, a.y); }
+            const float2 b = pj[nn + el];
+            sx = __fadd_rn(sx, b.x); sy = __fadd_rn(sy, b.y);
+        }
+        if (g.r > 0) { const float2 a = g.pieces[(size_t)(i + g.q) * (2 * nn) + el]; sx = __fadd_rn(sx, a.x); sy = __fadd_rn(sy, a.y); }
+        float2 r = make_float2(__fmul_rn(sx, g.inv_k), __fmul_rn(sy, g.inv_k));
+        if (g.gain) {                                      // fused antenna correction: R[a,b] *= g_a conj(g_b)
+            const float2 w = g.gain[el];
+            r = make_float2(fmaf(w.x, r.x, -w.y * r.y), fmaf(w.x, r.y, w.y * r.x));
+        }
+        return r;
+    };
+    float2 r = window_sum(e);
+    if (g.avg == 1) {                                      // (J conj(R) J)[a,b] = conj(R[N-1-a, N-1-b]) = element N^2-1-e
+        const float2 m = window_sum(nn - 1 - e);
+        r.x = __fadd_rn(__fmul_rn(0.5f, r.x), __fmul_rn(g.fb_hk, m.x));
+        r.y = __fadd_rn(__fmul_rn(0.5f, r.y), __fmul_rn(g.fb_hk, -m.y));
+    }
+    g.out[idx] = r;
+}
+
 // Wide arrays (8 < N <= 16): the per-snapshot outer-product sum is a 16 x K by K x 16 complex GEMM,
 // run on the matrix cores as four real v_mfma_f32_16x16x4_f32 per 4-sample step (exact fp32, same
 // rate as the vector FMA pipe but with the whole 16 x 16 accumulator held in 8 registers):
@@ -267,8 +406,24 @@ static int cov_waves_per_cu()
     return v;
 }
 
+// the read-once two-kernel path (see cov_piece_kernel)
+template <int TN> static void launch_pieces(const CovArgs &g, hipStream_t st)
+{
+    const int waves_per_block = 4;
+    int blocks = (g.n_steps + waves_per_block - 1) / waves_per_block;
+    if (cov_waves_per_cu() > 0) {
+        const int cap = 256 * cov_waves_per_cu() / waves_per_block;
+        if (blocks > cap) blocks = cap;
+    }
+    constexpr int UN = (TN <= 4) ? 4 : ((TN <= 6) ? 2 : 1);
+    hipLaunchKernelGGL((cov_piece_kernel<TN, UN, true>), dim3(blocks), dim3(waves_per_block * kWave), 0, st, g);
+    const long long total = (long long)g.n_out * g.n_ch * g.n_ch;
+    hipLaunchKernelGGL(cov_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g);
+}
+
 template <int TN> static void launch_wave(const CovArgs &g, bool vec2, hipStream_t st)
 {
+    if (g.pieces) { launch_pieces<TN>(g, st); return; }
     const int waves_per_block = 4;
     int blocks = (g.n_out + waves_per_block - 1) / waves_per_block;
     if (cov_waves_per_cu() > 0) {
@@ -289,8 +444,18 @@ template <int TN> static void launch_wave(const CovArgs &g, bool vec2, hipStream
 }
 
 // Launches K1 on `st`.  d_in: N device pointers.  Returns DOA_OK / error.
+// bytes of piece-sum workspace launch_autocorrelate wants for n_out windows (0: the shape does not
+// take the read-once path)
+size_t autocorrelate_workspace_bytes(int N, int K, int ovl, int n_out)
+{
+    static const int on = [] { const char *e = getenv("DOA_COV_PIECES"); return e ? atoi(e) : 1; }();
+    const int S = K - ovl;
+    if (!on || ovl <= 0 || N > 8 || n_out <= 0 || (S & 1) || ((K % S) & 1)) return 0;
+    return (size_t)(n_out + K / S) * 2 * N * N * sizeof(float2);
+}
+
 int launch_autocorrelate(int N, int K, int ovl, int avg, int n_out, const void *const *d_in, void *d_out,
-                         hipStream_t st, const void *d_gain_outer)
+                         hipStream_t st, const void *d_gain_outer, void *d_workspace)
 {
     if (n_out <= 0) return DOA_OK;
     CovArgs g;
@@ -308,6 +473,10 @@ int launch_autocorrelate(int N, int K, int ovl, int avg, int n_out, const void *
     g.inv_k = (float)(1.0 / K);
     g.fb_hk = (float)(0.5 / K);
     g.gain = static_cast<const float2 *>(d_gain_outer);
+    if (d_workspace && vec2 && autocorrelate_workspace_bytes(N, K, ovl, n_out) > 0) {
+        g.pieces = static_cast<float2 *>(d_workspace);
+        g.q = K / g.S; g.r = K % g.S; g.n_steps = n_out + g.q;
+    }
     switch (N) {
     case 1: launch_wave<1>(g, vec2, st); break;
     case 2: launch_wave<2>(g, vec2, st); break;
@@ -343,7 +512,7 @@ struct doa_autocorrelate {
     int inputs, snapshot, overlap, avg;
     int device;
     hipStream_t stream = nullptr;
-    doa::DevBuf d_in, d_out, d_gain;
+    doa::DevBuf d_in, d_out, d_gain, d_work;
     bool has_gain = false;
 };
 
@@ -383,6 +552,7 @@ void doa_autocorrelate_destroy(doa_autocorrelate_t *h)
     h->d_in.release();
     h->d_out.release();
     h->d_gain.release();
+    h->d_work.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -429,9 +599,13 @@ int doa_autocorrelate_work_dev(doa_autocorrelate_t *h, int noutput_items, const 
         return DOA_ERR_INVALID_ARG;
     }
     if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
-    int rc = doa::launch_autocorrelate(h->inputs, h->snapshot, h->overlap, h->avg, noutput_items, d_input_items,
-                                       d_output_items0, static_cast<hipStream_t>(hip_stream),
-                                       h->has_gain ? h->d_gain.p : nullptr);
+    // piece-sum workspace of the read-once path (grow-only; growing frees the old buffer, which waits for the device)
+    const size_t ws = doa::autocorrelate_workspace_bytes(h->inputs, h->snapshot, h->overlap, noutput_items);
+    int rc = ws ? h->d_work.reserve(ws) : DOA_OK;
+    if (rc != DOA_OK) return rc;
+    rc = doa::launch_autocorrelate(h->inputs, h->snapshot, h->overlap, h->avg, noutput_items, d_input_items,
+                                   d_output_items0, static_cast<hipStream_t>(hip_stream),
+                                   h->has_gain ? h->d_gain.p : nullptr, ws ? h->d_work.p : nullptr);
     return rc == DOA_OK ? noutput_items : rc;
 }
 
@@ -460,8 +634,11 @@ int doa_autocorrelate_work(doa_autocorrelate_t *h, int noutput_items, const void
         DOA_HIP_TRY(hipMemcpyAsync(dst, input_items[k], span * sizeof(float2), hipMemcpyHostToDevice, h->stream));
         d_ptrs[k] = dst;
     }
+    const size_t ws = doa::autocorrelate_workspace_bytes(N, h->snapshot, h->overlap, noutput_items);
+    if (ws) rc = h->d_work.reserve(ws);
+    if (rc != DOA_OK) return rc;
     rc = doa::launch_autocorrelate(N, h->snapshot, h->overlap, h->avg, noutput_items, d_ptrs, h->d_out.p, h->stream,
-                                   h->has_gain ? h->d_gain.p : nullptr);
+                                   h->has_gain ? h->d_gain.p : nullptr, ws ? h->d_work.p : nullptr);
     if (rc != DOA_OK) return rc;
     DOA_HIP_TRY(hipMemcpyAsync(output_items0, h->d_out.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
     DOA_HIP_TRY(hipStreamSynchronize(h->stream));

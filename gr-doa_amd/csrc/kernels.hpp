@@ -6,8 +6,9 @@ namespace doa {
 
 // K1  (autocorrelate.hip)
 // d_gain_outer: optional N*N float2 table w[a + b*N] = g_a conj(g_b) (fused antenna correction), or NULL
+size_t autocorrelate_workspace_bytes(int N, int K, int ovl, int n_out);
 int launch_autocorrelate(int N, int K, int ovl, int avg, int n_out, const void *const *d_in, void *d_out,
-                         hipStream_t st, const void *d_gain_outer = nullptr);
+                         hipStream_t st, const void *d_gain_outer = nullptr, void *d_workspace = nullptr);
 
 // Host-built tables of MUSIC_lin_array (music.hip): z_i = exp(j*psi_i), psi_i = k_i * d with
 // k_i = float(-2*pi*cos(theta_i)) on the reference's float-accumulated theta grid.

@@ -29,12 +29,13 @@ struct doa_music_pipeline {
     // host-pointer entry point only: two copy/compute lanes
     hipStream_t hst[2] = {nullptr, nullptr};
     doa::DevBuf d_in[2], d_res;
+    doa::DevBuf d_work[2];          // K1's piece sums (overlapping windows), one per copy/compute lane
 };
 
 // K1 -> EVD -> scan (+ peak) for n items on `st`; coefficient records at item offset `coef_off` of the
 // handle's workspace (chunks in flight on different streams must not share records).
 static int run_dev(doa_music_pipeline *h, int n, const void *const *d_in, void *cov, void *spec, void *mx, void *am,
-                   size_t item_off, hipStream_t st)
+                   size_t item_off, hipStream_t st, int lane = 0)
 {
     // DOA_PIPE_SKIP=cov,evd,scan: profiling aid that drops stages (outputs are then meaningless)
     unsigned skip = 0;      // read per call so that a profiling script can populate the intermediates first
@@ -45,7 +46,7 @@ static int run_dev(doa_music_pipeline *h, int n, const void *const *d_in, void *
     }
     int rc = DOA_OK;
     if (!(skip & 1)) rc = doa::launch_autocorrelate(h->N, h->K, h->ovl, h->avg, n, d_in, cov, st,
-                                                     h->has_gain ? h->d_gain.p : nullptr);
+                                                     h->has_gain ? h->d_gain.p : nullptr, h->d_work[lane].p);
     if (rc != DOA_OK) return rc;
     const bool dbl = (h->bits == 64);
     void *coef = static_cast<char *>(h->d_coef.p) + item_off * doa::coef_stride(h->N) * (dbl ? sizeof(double) : sizeof(float));
@@ -99,6 +100,8 @@ doa_music_pipeline_t *doa_music_pipeline_create(int inputs, int snapshot_size, i
     if (rc == DOA_OK) rc = h->d_cov.reserve((size_t)max_batch * inputs * inputs * sizeof(float2));
     if (rc == DOA_OK) rc = h->d_coef.reserve((size_t)max_batch * doa::coef_stride(inputs) * sizeof(double));
     if (rc == DOA_OK) rc = h->d_spec.reserve((size_t)max_batch * pspectrum_len * sizeof(float));
+    if (const size_t ws = doa::autocorrelate_workspace_bytes(inputs, snapshot_size, overlap_size, max_batch); ws && rc == DOA_OK)
+        rc = h->d_work[0].reserve(ws);
     if (rc != DOA_OK) {
         doa_music_pipeline_destroy(h);
         return nullptr;
@@ -113,6 +116,7 @@ void doa_music_pipeline_destroy(doa_music_pipeline_t *h)
     h->peaks.release();
     h->d_cov.release(); h->d_coef.release(); h->d_spec.release(); h->d_scratch.release(); h->d_gain.release();
     h->d_res.release();
+    for (auto &b : h->d_work) b.release();
     for (auto &b : h->d_in) b.release();
     for (auto st : h->hst)
         if (st) (void)hipStreamDestroy(st);
@@ -189,6 +193,8 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
     int rc = h->d_res.reserve((size_t)h->max_batch * M * 2 * sizeof(float));
     for (auto &b : h->d_in)
         if (rc == DOA_OK) rc = b.reserve(span_al * N * sizeof(float2));
+    if (const size_t ws = doa::autocorrelate_workspace_bytes(N, h->K, h->ovl, (int)chunk); ws && rc == DOA_OK)
+        rc = h->d_work[1].reserve(ws);                 // lane 0 uses the workspace create() sized for max_batch
     if (rc != DOA_OK) return rc;
     float *d_mx = h->d_res.as<float>(), *d_am = d_mx + (size_t)h->max_batch * M;
     int lane = 0;
@@ -205,7 +211,7 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
         }
         float2 *cov = h->d_cov.as<float2>() + s0 * N * N;
         float *spec = h->d_spec.as<float>() + s0 * P;
-        rc = run_dev(h, (int)n, d_ptrs, cov, spec, d_mx + s0 * M, d_am + s0 * M, s0, st);
+        rc = run_dev(h, (int)n, d_ptrs, cov, spec, d_mx + s0 * M, d_am + s0 * M, s0, st, lane);
         if (rc < 0) break;
         if (cov_out)
             DOA_HIP_TRY(hipMemcpyAsync(static_cast<float2 *>(cov_out) + s0 * N * N, cov, n * N * N * sizeof(float2),

@@ -17,9 +17,13 @@ ap.add_argument("--K", type=int, default=1024)
 ap.add_argument("--N", type=int, default=4)
 ap.add_argument("--P", type=int, default=1024)
 ap.add_argument("--M", type=int, default=1)
+ap.add_argument("--ovl", type=int, default=0, help="overlap_size (windows advance by K-ovl samples)")
+ap.add_argument("--fb", type=int, default=0, help="avg_method (1 = forward-backward)")
 ap.add_argument("--ablate", default="", help="mcov: multi-stream covariance only; mmusic: multi-stream MUSIC only")
 args = ap.parse_args()
 N, K, P, M, B = args.N, args.K, args.P, args.M, args.batch
+OVL, FB = args.ovl, args.fb
+STEP = K - OVL          # new samples per snapshot; a batch of B windows spans (B-1)*STEP + K samples
 doa.set_internal_precision(args.precision)
 st = torch.cuda.current_stream()
 streams = []
@@ -28,17 +32,17 @@ for b in range(args.nbuf):
         x = torch.randn((N, B * K, 2), device="cuda", dtype=torch.float32)
         streams.append([torch.view_as_complex(x[n].contiguous()) for n in range(N)])
     else:                                        # M sources at SNR 20 dB, a random direction set per snapshot
-        s_, _ = doa.sim.make_batch_streams_torch(N, K, B, 0.5, M, 20.0, seed=b)
+        s_, _ = doa.sim.make_batch_streams_torch(N, K, B, 0.5, M, 20.0, seed=b)     # B*K >= (B-1)*STEP + K samples
         streams.append(s_)
 ptrs = [[t.data_ptr() for t in s] for s in streams]
 cov = [torch.empty((B, N * N), dtype=torch.complex64, device="cuda") for _ in range(args.nbuf)]
 spec = [torch.empty((B, P), dtype=torch.float32, device="cuda") for _ in range(args.nbuf)]
 mx = [torch.empty((B, M), dtype=torch.float32, device="cuda") for _ in range(args.nbuf)]
 am = [torch.empty((B, M), dtype=torch.float32, device="cuda") for _ in range(args.nbuf)]
-cov_blk = doa.autocorrelate(N, K, 0, 0)
+cov_blk = doa.autocorrelate(N, K, OVL, FB)
 music_blk = doa.MUSIC_lin_array(0.5, M, N, P)
 peak_blk = doa.find_local_max(M, P, 0.0, 180.0)
-pipe = doa.music_pipeline(N, K, 0, 0, 0.5, M, P, B)
+pipe = doa.music_pipeline(N, K, OVL, FB, 0.5, M, P, B)
 
 def timeit(fn):
     for i in range(10): fn(i)
@@ -57,7 +61,7 @@ for i in range(nb):   # valid covariances in every buffer for the music stage
     cov_blk.work_dev(B, ptrs[i], cov[i].data_ptr(), st)
 if "cov" in args.stages:
     res["cov_us"] = timeit(lambda i: cov_blk.work_dev(B, ptrs[i % nb], cov[i % nb].data_ptr(), st))
-    res["cov_GBs"] = (N * K * 8 + N * N * 8) * B / res["cov_us"][0] / 1e3
+    res["cov_GBs"] = (N * STEP * 8 + N * N * 8) * B / res["cov_us"][0] / 1e3      # new samples only: the halo is a cache re-read
 if "music" in args.stages:
     res["music_us"] = timeit(lambda i: music_blk.work_dev(B, cov[i % nb].data_ptr(), spec[i % nb].data_ptr(), st))
 if "peak" in args.stages:
@@ -79,7 +83,7 @@ if "mpipe" in args.stages:
     # alternate steps over several streams, one pipeline handle (= workspace) per stream
     S = args.streams
     sts = [torch.cuda.Stream() for _ in range(S)]
-    pipes = [doa.music_pipeline(N, K, 0, 0, 0.5, M, P, B) for _ in range(S)]
+    pipes = [doa.music_pipeline(N, K, OVL, FB, 0.5, M, P, B) for _ in range(S)]
     def run(n):
         for i in range(n):
             k = i % S
