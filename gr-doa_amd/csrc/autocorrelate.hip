@@ -10,8 +10,8 @@
 // 16-byte (two-sample) loads from every channel — a wave instruction covers 1 KiB contiguous per
 // channel — and keeps the Hermitian upper triangle (N real + N(N-1)/2 complex partial sums) in
 // registers; partials meet in one DPP wave all-reduce and lanes 0..N^2-1 write the 8N^2-byte item
-// as one contiguous segment.  No LDS, no atomics; with overlapping windows the re-read halo is
-// served by L2.  8 < N <= 16 runs on the matrix cores (cov_mfma_kernel).
+// as one contiguous segment.  No LDS, no atomics.  Overlapping windows take a read-once two-kernel
+// path (cov_piece_kernel + cov_combine_kernel); 8 < N <= 16 runs on the matrix cores (cov_mfma_kernel).
 #include "common.hpp"
 
 #include <cstdlib>
