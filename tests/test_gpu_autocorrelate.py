@@ -36,6 +36,9 @@ CASES = [
     (1024, 0, 4, 0), (1024, 0, 4, 1), (1000, 1, 4, 1), (77, 10, 3, 1), (129, 0, 5, 0),
     (64, 63, 2, 1), (512, 128, 1, 0), (300, 100, 6, 1), (256, 0, 7, 0),
     (256, 32, 16, 1), (100, 7, 12, 1), (128, 0, 9, 0),
+    # read-once piece path (K = q S + r): q >= 2, r == 0, tiny steps, odd r (falls back to the single kernel)
+    (1024, 512, 4, 1), (1024, 768, 4, 0), (1000, 700, 3, 1), (96, 80, 8, 1), (100, 90, 2, 0),
+    (1024, 1022, 4, 1), (514, 2, 5, 1), (1001, 333, 4, 0), (90, 45, 4, 1),
 ]
 
 
