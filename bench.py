@@ -50,7 +50,7 @@ def algorithmic_bytes():
             "fused_total": fused, "scan_fused": rec + P_SPEC * 4 + 2 * M_SRC * 4}
 
 
-def scan_kernel_roofline(doa, torch, st, batch=262144, reps=10):
+def scan_kernel_roofline(doa, torch, st, batch=262144, reps=30):
     """The spectrum-scan kernel (K4, with K5 fused) in isolation, at a batch large enough that launch
     ramp/tail do not dominate (1 GiB of spectra): coefficient records are produced once by a real
     K1 -> EVD pass over short (64-sample) snapshots, then only the scan launch is repeated."""
@@ -67,7 +67,7 @@ def scan_kernel_roofline(doa, torch, st, batch=262144, reps=10):
     torch.cuda.synchronize()
     os.environ["DOA_PIPE_SKIP"] = "cov,evd"          # read per call by the pipeline (diagnostic switch)
     try:
-        for _ in range(5):
+        for _ in range(30):                      # sustained warm-up: the first ~50 launches run measurably slower
             run()
         groups = []
         for _ in range(5):
@@ -168,8 +168,8 @@ def cpu_baseline(budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
                     help="internal precision of EVD + scan (items are fp32 either way)")
     ap.add_argument("--nbuf", type=int, default=6, help="distinct batches rotated through (defeats L3 residency)")
