@@ -394,54 +394,18 @@ template <int G, typename T, int ROUND> struct RoundLoop {
     }
 };
 
+// Shared epilogue of the group kernels: lane r of a G-lane group (lanes base .. base+G-1) holds row r
+// of V (columns = eigenvector slots) and the eigenvalue lam of slot r; real_col = slot r belongs to
+// the N x N problem (not padding).  Ranks the eigenvalues ascending (the eig_sym contract), takes the
+// N-M smallest as the noise set and emits the diagonal sums u_l of P_N (or, in calibrate mode, the
+// de-rotated top eigenvector).
 template <int G, typename T>
-__global__ __launch_bounds__(64) void music_evd_group_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
-                                                             double *__restrict__ coef_d, float2 *__restrict__ pn_out,
-                                                             int n_items, int N, int M,
-                                                             const float2 *__restrict__ pilot, float2 *__restrict__ cal_out)
+__device__ __forceinline__ void evd_group_epilogue(T (&vr)[G], T (&vi)[G], T lam, bool real_col, int r, int base, int lane,
+                                                   int item, bool real_item, int N, int M, float *__restrict__ coef,
+                                                   double *__restrict__ coef_d, float2 *__restrict__ pn_out,
+                                                   const float2 *__restrict__ pilot, float2 *__restrict__ cal_out)
 {
-    constexpr int IPW = kWave / G;                       // items per wave
-    const int lane = threadIdx.x & (kWave - 1);
-    const int r = lane % G, base = lane - r;
-    int item = blockIdx.x * IPW + lane / G;
-    const bool real_item = item < n_items;
-    if (!real_item) item = n_items - 1;                  // idle groups shadow the last item (no stores)
-    const float2 *Ri = R + (size_t)item * (N * N);
-
-    T ar[G], ai[G], vr[G], vi[G];
-#pragma unroll
-    for (int c = 0; c < G; c++) {
-        T xr = 0, xi = 0;
-        if (r < N && c < N) {
-            // upper triangle only (cheevd uplo='U'): A[r][c] = R[r + c N] for r <= c, else conj(R[c + r N])
-            const float2 x = (r <= c) ? Ri[r + c * N] : Ri[c + r * N];
-            xr = (T)x.x;
-            xi = (r == c) ? (T)0 : ((r < c) ? (T)x.y : -(T)x.y);
-        } else if (r == c) {
-            xr = (T)1e30;                                // padding: isolated, ranks after every real eigenvalue
-        }
-        ar[c] = xr; ai[c] = xi;
-        vr[c] = (r == c) ? (T)1 : (T)0; vi[c] = 0;
-    }
-    const int max_sweeps = Real<T>::max_sweeps + G;
-    bool active = true;
-    for (int sweep = 0; sweep < max_sweeps; sweep++) {
-        T off = 0, dn = 0;
-#pragma unroll
-        for (int k = 0; k < G; k++) {
-            const T m = ar[k] * ar[k] + ai[k] * ai[k];
-            if (r < N && k < N) { if (k == r) dn += m; else off += m; }
-        }
-        off = group_sum<G, T>(off, lane);
-        dn = group_sum<G, T>(dn, lane);
-        active = active && (off > Real<T>::tol * dn) && (off > Real<T>::tiny);
-        if (!__any(active)) break;
-        RoundLoop<G, T, 0>::run(ar, ai, vr, vi, r, base, active);
-    }
     // eigenvalue of lane r = A[r][r]; ascending rank inside the group; noise set = ranks < N-M
-    T lam = 0;
-#pragma unroll
-    for (int k = 0; k < G; k++) lam = (k == r) ? ar[k] : lam;
     int rank = 0;
 #pragma unroll
     for (int j = 0; j < G; j++) {
@@ -452,7 +416,7 @@ __global__ __launch_bounds__(64) void music_evd_group_kernel(const float2 *__res
         // calibrate_lin_array (reference lib/calibrate_lin_array_impl.cc:98-134): U_S = eigenvector of the
         // largest eigenvalue; W = diag(conj v) U_S U_S^H diag(v) is rank one, so its unit-eigenvalue
         // eigenvector is conj(v) .* U_S (normalised).  Phase convention: element 0 real, non-negative.
-        const unsigned long long top_mask = __ballot((r < N) && (rank == N - 1));
+        const unsigned long long top_mask = __ballot(real_col && (rank == N - 1));
         const int imax = __builtin_ctzll(((top_mask >> base) & ((1ull << G) - 1ull)) | (1ull << G));   // column of the top eigenvector
         T er = 0, ei = 0;
 #pragma unroll
@@ -475,7 +439,7 @@ __global__ __launch_bounds__(64) void music_evd_group_kernel(const float2 *__res
         if (real_item && r < N) cal_out[(size_t)item * N + r] = make_float2((float)wr, (float)((r == 0) ? (T)0 : wi));
         return;
     }
-    const bool is_noise = (r < N) && (rank < N - M);
+    const bool is_noise = real_col && (rank < N - M);
     const unsigned long long noise_mask = __ballot(is_noise);
     const unsigned sel = (unsigned)((noise_mask >> base) & ((1ull << G) - 1ull));     // bit i: column i is a noise vector
     // masked columns: Y = V S
@@ -530,6 +494,288 @@ __global__ __launch_bounds__(64) void music_evd_group_kernel(const float2 *__res
 }
 
 template <int G, typename T>
+__global__ __launch_bounds__(64) void music_evd_group_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
+                                                             double *__restrict__ coef_d, float2 *__restrict__ pn_out,
+                                                             int n_items, int N, int M,
+                                                             const float2 *__restrict__ pilot, float2 *__restrict__ cal_out)
+{
+    constexpr int IPW = kWave / G;                       // items per wave
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r = lane % G, base = lane - r;
+    int item = blockIdx.x * IPW + lane / G;
+    const bool real_item = item < n_items;
+    if (!real_item) item = n_items - 1;                  // idle groups shadow the last item (no stores)
+    const float2 *Ri = R + (size_t)item * (N * N);
+
+    T ar[G], ai[G], vr[G], vi[G];
+#pragma unroll
+    for (int c = 0; c < G; c++) {
+        T xr = 0, xi = 0;
+        if (r < N && c < N) {
+            // upper triangle only (cheevd uplo='U'): A[r][c] = R[r + c N] for r <= c, else conj(R[c + r N])
+            const float2 x = (r <= c) ? Ri[r + c * N] : Ri[c + r * N];
+            xr = (T)x.x;
+            xi = (r == c) ? (T)0 : ((r < c) ? (T)x.y : -(T)x.y);
+        } else if (r == c) {
+            xr = (T)1e30;                                // padding: isolated, ranks after every real eigenvalue
+        }
+        ar[c] = xr; ai[c] = xi;
+        vr[c] = (r == c) ? (T)1 : (T)0; vi[c] = 0;
+    }
+    const int max_sweeps = Real<T>::max_sweeps + G;
+    bool active = true;
+    for (int sweep = 0; sweep < max_sweeps; sweep++) {
+        T off = 0, dn = 0;
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const T m = ar[k] * ar[k] + ai[k] * ai[k];
+            if (r < N && k < N) { if (k == r) dn += m; else off += m; }
+        }
+        off = group_sum<G, T>(off, lane);
+        dn = group_sum<G, T>(dn, lane);
+        active = active && (off > Real<T>::tol * dn) && (off > Real<T>::tiny);
+        if (!__any(active)) break;
+        RoundLoop<G, T, 0>::run(ar, ai, vr, vi, r, base, active);
+    }
+    // eigenvalue of lane r = A[r][r]
+    T lam = 0;
+#pragma unroll
+    for (int k = 0; k < G; k++) lam = (k == r) ? ar[k] : lam;
+    evd_group_epilogue<G, T>(vr, vi, lam, r < N, r, base, lane, item, real_item, N, M, coef, coef_d, pn_out, pilot, cal_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 8 < N <= 16: one WAVE per item, lane (a, b) = (lane >> 3, lane & 7) holds the 2 x 2 block
+// A[2a..2a+1][2b..2b+1] and the same block of V.  Pivot pairs sit at fixed physical positions
+// (2k, 2k+1) (Brent-Luk): every round the diagonal lane (k, k) builds the rotation of its own block,
+// lane (a, b) applies J_a^H from the left and J_b from the right (V: J_b only), and then rows and
+// columns move one step along the round-robin "caterpillar" (position 0 fixed), so that after 15
+// rounds every index pair has met once.  Rounds are a rolled loop of identical code; the state is 16
+// registers per matrix instead of the 64 the row-per-lane layout needs at G = 16 (which compiles to
+// 512 VGPRs + scratch, i.e. one wave per SIMD whatever the batch), so 4096 items run as 4+ waves per
+// SIMD and the cross-lane latency of one item hides behind the arithmetic of the others.
+// Padding (N < 16): zero rows/columns -- never rotated (pivot 0 -> identity), they only travel; a
+// 16-bit mask that takes the same permutation tells the epilogue which slots are padding.
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T wave_sum_t(T v)
+{
+#pragma unroll
+    for (int m = 1; m < kWave; m <<= 1) v += lane_fetch<T>(v, (int)((threadIdx.x & (kWave - 1)) ^ m));
+    return v;
+}
+
+// one caterpillar step: new[0]=old[0], new[2]=old[1], new[2m]=old[2m-2] (m>=2), new[2m-1]=old[2m+1] (m<=7), new[15]=old[14]
+__device__ __forceinline__ unsigned caterpillar_mask(unsigned m)
+{
+    unsigned n = (m & 1u) | (((m >> 1) & 1u) << 2) | (((m >> 14) & 1u) << 15);
+#pragma unroll
+    for (int k = 2; k <= 7; k++) n |= ((m >> (2 * k - 2)) & 1u) << (2 * k);
+#pragma unroll
+    for (int k = 1; k <= 7; k++) n |= ((m >> (2 * k + 1)) & 1u) << (2 * k - 1);
+    return n;
+}
+
+// LEAN: production outputs only (the coefficient records); its epilogue works out of LDS on all 64
+// lanes, so the kernel's register allocation is that of the sweeps (the row-per-lane epilogue alone
+// needs ~200 VGPRs in double, which would halve the resident waves).  !LEAN: diagnostics (P_N) and
+// calibrate mode through the shared row-per-lane epilogue.
+template <typename T, bool LEAN>
+__global__ __launch_bounds__(64) void music_evd_block16_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
+                                                               double *__restrict__ coef_d, float2 *__restrict__ pn_out,
+                                                               int n_items, int N, int M,
+                                                               const float2 *__restrict__ pilot, float2 *__restrict__ cal_out)
+{
+    constexpr int G = 16;
+    __shared__ T sVr[G * G], sVi[G * G], sLam[G];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int a = lane >> 3, b = lane & 7;
+    const int item = blockIdx.x;                         // grid = n_items
+    const float2 *Ri = R + (size_t)item * (N * N);
+    T xr[2][2], xi[2][2], vr[2][2], vi[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int row = 2 * a + i, col = 2 * b + j;
+            T re = 0, im = 0;
+            if (row < N && col < N) {
+                // upper triangle only (cheevd uplo='U'): A[r][c] = R[r + c N] for r <= c, else conj(R[c + r N])
+                const float2 x = (row <= col) ? Ri[row + col * N] : Ri[col + row * N];
+                re = (T)x.x;
+                im = (row == col) ? (T)0 : ((row < col) ? (T)x.y : -(T)x.y);
+            }
+            xr[i][j] = re; xi[i][j] = im;
+            vr[i][j] = (row == col) ? (T)1 : (T)0; vi[i][j] = 0;
+        }
+    unsigned pad = (N >= G) ? 0u : (((1u << G) - 1u) & ~((1u << N) - 1u));      // bit k: physical slot k is padding
+    const int src_a = 9 * a, src_b = 9 * b;              // diagonal lanes (a,a) and (b,b)
+    const int ln_l = (lane + kWave - 1) & (kWave - 1), ln_r = (lane + 1) & (kWave - 1);
+    const int ln_u = (lane + kWave - 8) & (kWave - 1), ln_d = (lane + 8) & (kWave - 1);
+    const int max_sweeps = Real<T>::max_sweeps + G;
+    for (int sweep = 0; sweep < max_sweeps; sweep++) {
+        T off = 0, dn = 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const T m = xr[i][j] * xr[i][j] + xi[i][j] * xi[i][j];
+                if (a == b && i == j) dn += m; else off += m;
+            }
+        off = wave_sum_t<T>(off);
+        dn = wave_sum_t<T>(dn);
+        if (!((off > Real<T>::tol * dn) && (off > Real<T>::tiny))) break;       // wave-uniform: one item per wave
+#pragma unroll 1
+        for (int round = 0; round < G - 1; round++) {
+            // rotation of the own 2 x 2 block (meaningful on the diagonal lanes, harmless elsewhere)
+            const T d_p = xr[0][0], d_q = xr[1][1], pr = xr[0][1], pi = xi[0][1];
+            const T g2 = pr * pr + pi * pi;
+            const bool live = g2 > Real<T>::tiny;
+            const T inv_g = Real<T>::rsqrt(live ? g2 : (T)1);
+            const T phr = pr * inv_g, phi = pi * inv_g;
+            T tau = (d_q - d_p) * (T)0.5 * inv_g;
+            tau = fmin(fmax(tau, -Real<T>::tau_max), Real<T>::tau_max);
+            const T x1 = fma(tau, tau, (T)1);
+            const T rt = x1 * Real<T>::rsqrt(x1);
+            const T h = fabs(tau) + rt;
+            const T w = Real<T>::rsqrt(fma(h, h, (T)1));
+            const T c_mine = live ? h * w : (T)1;
+            const T s_mine = live ? copysign(w, tau) : (T)0;
+            const T sr_mine = s_mine * phr, si_mine = s_mine * phi;              // sigma = J[p][q]
+            const T ca = lane_fetch<T>(c_mine, src_a), sar = lane_fetch<T>(sr_mine, src_a), sai = lane_fetch<T>(si_mine, src_a);
+            const T cb = lane_fetch<T>(c_mine, src_b), sbr = lane_fetch<T>(sr_mine, src_b), sbi = lane_fetch<T>(si_mine, src_b);
+            // columns: (P, Q) <- (c P - conj(sigma) Q, c Q + sigma P) with the pair of column block b
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                {
+                    const T p_r = xr[i][0], p_i = xi[i][0], q_r = xr[i][1], q_i = xi[i][1];
+                    xr[i][0] = cb * p_r - (sbr * q_r + sbi * q_i);
+                    xi[i][0] = cb * p_i - (sbr * q_i - sbi * q_r);
+                    xr[i][1] = cb * q_r + (sbr * p_r - sbi * p_i);
+                    xi[i][1] = cb * q_i + (sbr * p_i + sbi * p_r);
+                }
+                {
+                    const T p_r = vr[i][0], p_i = vi[i][0], q_r = vr[i][1], q_i = vi[i][1];
+                    vr[i][0] = cb * p_r - (sbr * q_r + sbi * q_i);
+                    vi[i][0] = cb * p_i - (sbr * q_i - sbi * q_r);
+                    vr[i][1] = cb * q_r + (sbr * p_r - sbi * p_i);
+                    vi[i][1] = cb * q_i + (sbr * p_i + sbi * p_r);
+                }
+            }
+            // rows of A: (p, q) <- (c p - sigma q, c q + conj(sigma) p) with the pair of row block a
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const T p_r = xr[0][j], p_i = xi[0][j], q_r = xr[1][j], q_i = xi[1][j];
+                xr[0][j] = ca * p_r - (sar * q_r - sai * q_i);
+                xi[0][j] = ca * p_i - (sar * q_i + sai * q_r);
+                xr[1][j] = ca * q_r + (sar * p_r + sai * p_i);
+                xi[1][j] = ca * q_i + (sar * p_i - sai * p_r);
+            }
+            // caterpillar step, columns (A and V): slot 0 <- left neighbour, slot 1 <- right neighbour
+            auto move_cols = [&](T (&m)[2][2]) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const T to_right = (b == 0) ? m[i][1] : m[i][0];
+                    const T from_left = lane_fetch<T>(to_right, ln_l);
+                    const T from_right = lane_fetch<T>(m[i][1], ln_r);
+                    const T keep = m[i][0];
+                    m[i][0] = (b == 0) ? keep : from_left;
+                    m[i][1] = (b == 7) ? keep : from_right;
+                }
+            };
+            move_cols(xr); move_cols(xi); move_cols(vr); move_cols(vi);
+            // rows (A only): row 0 <- block row above, row 1 <- block row below
+            auto move_rows = [&](T (&m)[2][2]) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const T to_down = (a == 0) ? m[1][j] : m[0][j];
+                    const T from_up = lane_fetch<T>(to_down, ln_u);
+                    const T from_down = lane_fetch<T>(m[1][j], ln_d);
+                    const T keep = m[0][j];
+                    m[0][j] = (a == 0) ? keep : from_up;
+                    m[1][j] = (a == 7) ? keep : from_down;
+                }
+            };
+            move_rows(xr); move_rows(xi);
+            pad = caterpillar_mask(pad);
+        }
+    }
+    // hand the result to the row-per-lane epilogue through LDS: V[row][slot], lam[slot]
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            sVr[(2 * a + i) * G + 2 * b + j] = vr[i][j];
+            sVi[(2 * a + i) * G + 2 * b + j] = vi[i][j];
+        }
+    if (a == b) {
+        sLam[2 * a] = ((pad >> (2 * a)) & 1u) ? (T)1e30 : xr[0][0];             // padding ranks after every real eigenvalue
+        sLam[2 * a + 1] = ((pad >> (2 * a + 1)) & 1u) ? (T)1e30 : xr[1][1];
+    }
+    __syncthreads();
+    if constexpr (LEAN) {
+        // ranks (ascending, ties -> lower slot) on lanes 0..15; noise set = the N-M smallest real slots
+        bool is_noise = false;
+        if (lane < G) {
+            const T lam = sLam[lane];
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                const T lj = sLam[j];
+                rank += ((lj < lam) || (lj == lam && j < lane)) ? 1 : 0;
+            }
+            is_noise = !((pad >> lane) & 1u) && (rank < N - M);
+        }
+        const unsigned sel = (unsigned)(__ballot(is_noise) & 0xFFFFull);
+        // u_l = sum_r sum_{i in noise} V[r+l][i] conj(V[r][i]):  lane = 4 l + c takes the rows r = c (mod 4)
+        const int l = lane >> 2, c4 = lane & 3;
+        T tr = 0, ti = 0;
+        if (l < N) {
+            for (int r = c4; r + l < N; r += 4) {
+                const T *ur = sVr + (r + l) * G, *ui = sVi + (r + l) * G, *wr = sVr + r * G, *wi = sVi + r * G;
+#pragma unroll
+                for (int i = 0; i < G; i++)
+                    if ((sel >> i) & 1u) {
+                        tr = fma(ur[i], wr[i], fma(ui[i], wi[i], tr));
+                        ti = fma(ui[i], wr[i], fma(-ur[i], wi[i], ti));
+                    }
+            }
+        }
+        tr += lane_fetch<T>(tr, lane ^ 1); ti += lane_fetch<T>(ti, lane ^ 1);
+        tr += lane_fetch<T>(tr, lane ^ 2); ti += lane_fetch<T>(ti, lane ^ 2);
+        if (c4 == 0 && l < N) {
+            float *co = coef ? coef + (size_t)item * (2 * N) : nullptr;
+            double *cd = coef_d ? coef_d + (size_t)item * (2 * N) : nullptr;
+            if (l == 0) {
+                if (co) { co[0] = (float)tr; co[2 * N - 1] = 0.f; }
+                if (cd) { cd[0] = (double)tr; cd[2 * N - 1] = 0.0; }
+            } else {
+                if (co) { co[2 * l - 1] = (float)tr; co[2 * l] = (float)ti; }
+                if (cd) { cd[2 * l - 1] = (double)tr; cd[2 * l] = (double)ti; }
+            }
+        }
+    } else if (lane < G) {
+        T er[G], ei[G];
+#pragma unroll
+        for (int k = 0; k < G; k++) { er[k] = sVr[lane * G + k]; ei[k] = sVi[lane * G + k]; }
+        evd_group_epilogue<G, T>(er, ei, sLam[lane], !((pad >> lane) & 1u), lane, 0, lane, item, true, N, M, coef, coef_d,
+                                 pn_out, pilot, cal_out);
+    }
+}
+
+template <typename T>
+static void launch_evd_block16(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
+                               hipStream_t st, const void *d_pilot = nullptr, void *d_cal = nullptr)
+{
+    if (!d_pn && !d_cal)
+        hipLaunchKernelGGL((music_evd_block16_kernel<T, true>), dim3(n_items), dim3(64), 0, st, (const float2 *)d_R,
+                           (float *)d_coef, (double *)d_coef_d, nullptr, n_items, N, M, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((music_evd_block16_kernel<T, false>), dim3(n_items), dim3(64), 0, st, (const float2 *)d_R,
+                           (float *)d_coef, (double *)d_coef_d, (float2 *)d_pn, n_items, N, M, (const float2 *)d_pilot,
+                           (float2 *)d_cal);
+}
+
+template <int G, typename T>
 static void launch_evd_group(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
                              hipStream_t st, const void *d_pilot = nullptr, void *d_cal = nullptr)
 {
@@ -577,7 +823,11 @@ int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, v
     // the matrices in scratch).  DOA_EVD_KERNEL=1 forces the group kernel for N <= 4 (A/B runs).
     static const int force_group = [] { const char *e = getenv("DOA_EVD_KERNEL"); return e ? atoi(e) : 0; }();
     const bool f32 = (evd_bits == 32);
-    if (N > 8) {
+    static const int block16 = [] { const char *e = getenv("DOA_EVD16_BLOCK"); return e ? atoi(e) : 1; }();
+    if (N > 8 && block16) {
+        if (f32) launch_evd_block16<float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
+        else launch_evd_block16<double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
+    } else if (N > 8) {
         if (f32) launch_evd_group<16, float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
         else launch_evd_group<16, double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
     } else if (N > 4) {
