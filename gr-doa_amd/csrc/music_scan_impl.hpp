@@ -84,10 +84,15 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
     }
     // coefficient records arrive through scalar loads (wave-uniform address); the next item's record
     // is requested before this item's arithmetic so its latency hides behind it
-    T c[2 * N], c_next[2 * N];
-    if (wave < n_items) {
+    // (records of more than 64 dwords -- N > 8 in double -- are not double-buffered: two of them do not fit
+    // the scalar register file and end up in VGPRs, which the long-spectrum variants cannot spare)
+    constexpr bool PREFETCH = (2 * N * sizeof(T) <= 256);
+    T c[2 * N], c_next[PREFETCH ? 2 * N : 1];
+    if constexpr (PREFETCH) {
+        if (wave < n_items) {
 #pragma unroll
-        for (int k = 0; k < 2 * N; k++) c_next[k] = (k < rec - 1) ? coef[(size_t)wave * rec + k] : (T)0;
+            for (int k = 0; k < 2 * N; k++) c_next[k] = (k < rec - 1) ? coef[(size_t)wave * rec + k] : (T)0;
+        }
     }
     // One item: Q at this lane's 4*CH angles, 1/Q, wave maximum, dB, stores, optional peak pick.
     // FULL (P == 256*CH, the usual power-of-two lengths) drops every bounds predicate.
@@ -95,6 +100,11 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
         constexpr bool FULL = decltype(full_tag)::value;
         float out[CH][4];
         float mx = -INFINITY;
+        // !ZREG: the table loads do not depend on the item, so the optimiser would hoist them out of the
+        // item loop and rebuild the register-resident table this variant exists to avoid (432-512 VGPRs at
+        // CH = 16): launder the pointer once per item
+        const T *zt = ztab;
+        if constexpr (!ZREG) asm volatile("" : "+s"(zt));
 #pragma unroll
         for (int j = 0; j < CH; j++) {
             const bool live = FULL || ((4 * lane + 256 * j) < P);
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
                 const int i0 = 4 * lane + 256 * j;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    if (live) { zr[0][e] = ztab[2 * (i0 + e)]; zi[0][e] = ztab[2 * (i0 + e) + 1]; }
+                    if (live) { zr[0][e] = zt[2 * (i0 + e)]; zi[0][e] = zt[2 * (i0 + e) + 1]; }
                     else { zr[0][e] = 1; zi[0][e] = 0; }
                 }
             }
@@ -115,6 +125,9 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
                 out[j][e] = __builtin_amdgcn_rcpf(q);           // 1.0/Q  (:140)
                 mx = live ? fmaxf(mx, out[j][e]) : mx;
             }
+            // table re-read per chunk: keep the scheduler from hoisting all CH chunks' loads to the top
+            // (16 chunks x 8 doubles of table = 256 VGPRs, i.e. one wave per SIMD and spills)
+            if constexpr (!ZREG) __builtin_amdgcn_sched_barrier(0);
         }
         mx = wave_allreduce_max(mx);
         float *row = spec + (size_t)item * P;
@@ -166,12 +179,17 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
     };
     const bool full = (P == 256 * CH);
     for (int item = wave; item < n_items; item += n_waves) {
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int k = 0; k < 2 * N; k++) c[k] = c_next[k];
-        const int nxt = item + n_waves;
-        if (nxt < n_items) {
+            for (int k = 0; k < 2 * N; k++) c[k] = c_next[k];
+            const int nxt = item + n_waves;
+            if (nxt < n_items) {
 #pragma unroll
-            for (int k = 0; k < 2 * N; k++) c_next[k] = (k < rec - 1) ? coef[(size_t)nxt * rec + k] : (T)0;
+                for (int k = 0; k < 2 * N; k++) c_next[k] = (k < rec - 1) ? coef[(size_t)nxt * rec + k] : (T)0;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2 * N; k++) c[k] = (k < rec - 1) ? coef[(size_t)item * rec + k] : (T)0;
         }
         if (full) do_item(item, std::true_type{});
         else do_item(item, std::false_type{});
