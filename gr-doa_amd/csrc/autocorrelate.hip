@@ -412,7 +412,7 @@ template <int TN> static void launch_pieces(const CovArgs &g, hipStream_t st)
     const int waves_per_block = 4;
     int blocks = (g.n_steps + waves_per_block - 1) / waves_per_block;
     if (cov_waves_per_cu() > 0) {
-        const int cap = 256 * cov_waves_per_cu() / waves_per_block;
+        const int cap = cu_count() * cov_waves_per_cu() / waves_per_block;
         if (blocks > cap) blocks = cap;
     }
     constexpr int UN = (TN <= 4) ? 4 : ((TN <= 6) ? 2 : 1);
@@ -427,7 +427,7 @@ template <int TN> static void launch_wave(const CovArgs &g, bool vec2, hipStream
     const int waves_per_block = 4;
     int blocks = (g.n_out + waves_per_block - 1) / waves_per_block;
     if (cov_waves_per_cu() > 0) {
-        const int cap = 256 * cov_waves_per_cu() / waves_per_block;
+        const int cap = cu_count() * cov_waves_per_cu() / waves_per_block;
         if (blocks > cap) blocks = cap;
     }
     dim3 grid(blocks), block(waves_per_block * kWave);
@@ -488,7 +488,7 @@ int launch_autocorrelate(int N, int K, int ovl, int avg, int n_out, const void *
     case 8: launch_wave<8>(g, vec2, st); break;
     default: {
         int blocks = (n_out + 3) / 4;
-        if (blocks > 256 * 4) blocks = 256 * 4;        // <= 16 waves per CU, grid-stride beyond
+        if (blocks > cu_count() * 4) blocks = cu_count() * 4;        // <= 16 waves per CU, grid-stride beyond
         if (vec2) hipLaunchKernelGGL(cov_mfma_kernel<true>, dim3(blocks), dim3(256), 0, st, g);
         else      hipLaunchKernelGGL(cov_mfma_kernel<false>, dim3(blocks), dim3(256), 0, st, g);
         if (avg == 1) {

@@ -33,6 +33,20 @@ int ensure_device(int *device_out)
     return DOA_OK;
 }
 
+int cu_count()
+{
+    // compute units of the current device (MI355X: 256), cached per device; launch caps scale with it
+    static std::atomic<int> cached[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+
 int bind_device(int device)
 {
     int cur = -1;

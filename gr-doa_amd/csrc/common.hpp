@@ -32,6 +32,8 @@ void clear_error();
 int ensure_device(int *device_out);
 // Makes `device` (the one the handle was created on) current for the calling thread if it is not.
 int bind_device(int device);
+// Compute units of the current device (cached); the grid caps of the streaming kernels are multiples of it.
+int cu_count();
 
 // ---- grow-only device / pinned-host buffers ----------------------------------------------------
 struct DevBuf {

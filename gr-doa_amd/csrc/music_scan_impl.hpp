@@ -426,7 +426,7 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
     // item's coefficient record is prefetched behind the current item's arithmetic
     int blocks = (n_items + waves_per_block - 1) / waves_per_block;
     static const int wpc = [] { const char *e = getenv("DOA_SCAN_WAVES_PER_CU"); return e ? atoi(e) : 8; }();
-    const int max_blocks = 256 * wpc / waves_per_block;
+    const int max_blocks = cu_count() * wpc / waves_per_block;
     if (blocks > max_blocks) blocks = max_blocks;
     dim3 grid(blocks), block(waves_per_block * kWave);
     // the lean benchmark-shape kernel (see music_scan_peak1_kernel)
@@ -434,7 +434,7 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
     if (lean && aligned && pk.val && pk.M >= 1 && !q && n_ant == N && (P == 256 || P == 512 || P == 1024)) {
         int lb = (n_items + waves_per_block - 1) / waves_per_block;
         static const int lwpc = [] { const char *e = getenv("DOA_SCAN_LEAN_WAVES_PER_CU"); return e ? atoi(e) : 8; }();
-        if (lb > 256 * lwpc / waves_per_block) lb = 256 * lwpc / waves_per_block;
+        if (lb > cu_count() * lwpc / waves_per_block) lb = cu_count() * lwpc / waves_per_block;
         dim3 lgrid(lb);
 #define DOA_LEAN_LAUNCH(CH_, MULTI_)                                                                              \
     hipLaunchKernelGGL((music_scan_peak1_kernel<N, CH_, T, MULTI_>), lgrid, block, 0, st, co, z, sp, n_items, pk.xaxis, \
