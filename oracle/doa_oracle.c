@@ -6,7 +6,7 @@
  * cpu_baseline leg.  PARITY STATUS: parity unpinned against the reference's own outputs (the
  * reference stores no golden vectors and cannot be built here: Armadillo, GNU Radio and Octave
  * are absent) — see the header of oracle/doa_oracle.py for what pins the oracle instead; this C
- * file is itself checked against that numpy/LAPACK oracle in tests/test_oracle_c.py.
+ * file is itself checked against that numpy/LAPACK oracle in tests/test_cpu_oracle_c.py.
  *
  * Each routine follows the per-item algorithm of the reference block it names (paths relative
  * to the reference tree):

@@ -13,7 +13,7 @@ sub-expressions the C++ promotes).
 PARITY STATUS: **parity unpinned** with respect to the reference's own outputs.  The reference
 stores no golden vectors (its QA tests mint inputs and expectations at run time through Octave,
 `python/qa_*.py`), and neither Armadillo, GNU Radio nor Octave exist in the build image, so the
-reference could not be run.  What pins this oracle instead (tests/test_oracle_*.py):
+reference could not be run.  What pins this oracle instead (tests/test_cpu_oracle_pins.py):
   * the reference's own deterministic QA scenario for find_local_max
     (`python/test001_findpeaks.m`, `python/test002_findpeaks.m`) checked against an independent
     peak finder (`scipy.signal.find_peaks`) to the reference's 5-decimal tolerance;
