@@ -20,6 +20,8 @@ reference could not be run.  What pins this oracle instead (tests/test_cpu_oracl
   * the reference's QA scenarios and tolerances for autocorrelate / MUSIC / Root-MUSIC
     (|dR| <= 1.0, |d angle| <= 2.0 deg: `python/qa_autocorrelate.py:82`,
     `python/qa_MUSIC_lin_array.py:96`, `python/qa_rootMUSIC_linear_array.py:87`) on seeded inputs;
+  * a numpy restatement of the reference's Octave golden model (examples/@wpi_twinrx_doa_testbench/
+    MUSIC.m, rMUSIC.m, autocorrelate.m), which the fp64 path below equals to rounding;
   * an fp64 evaluation (`precision="f64"`: zheevd/zgeev, double tables) of the same formulas.
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import this file.
