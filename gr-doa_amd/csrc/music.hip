@@ -790,7 +790,7 @@ int launch_calibrate(int N, int n_items, const void *d_R, const void *d_pilot, v
 {
     if (n_items <= 0) return DOA_OK;
     const bool f32 = (bits == 32);
-    if (N > 8) { if (f32) launch_evd_group<16, float>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); else launch_evd_group<16, double>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); }
+    if (N > 8) { if (f32) launch_evd_block16<float>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); else launch_evd_block16<double>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); }
     else if (N > 4) { if (f32) launch_evd_group<8, float>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); else launch_evd_group<8, double>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); }
     else { if (f32) launch_evd_group<4, float>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); else launch_evd_group<4, double>(N, 1, n_items, d_R, nullptr, nullptr, nullptr, st, d_pilot, d_out); }
     DOA_HIP_TRY(hipGetLastError());
