@@ -319,7 +319,12 @@ def _peak_indices_one(v: np.ndarray) -> np.ndarray:
 def _peak_indices_many(v: np.ndarray, num_max_vals: int) -> np.ndarray:
     """find_more_than_one_local_peak_indxs.  lib/find_local_max_impl.cc:80-165."""
     L = v.shape[0]
-    s = np.sign(np.diff(v)).astype(_F32)                          # :89
+    with np.errstate(invalid="ignore"):
+        d = np.diff(v)
+    # :89 sign(diff(in_vec)).  A NaN difference (NaN input, or inf - inf) is taken as sign 0, i.e. a flat --
+    # the three-way (x > 0) ? 1 : (x < 0) ? -1 : 0 form; an Armadillo whose sign() propagates NaN would differ,
+    # but non-finite vectors are outside anything the reference tests or can produce from finite input.
+    s = np.where(d > 0, 1.0, np.where(d < 0, -1.0, 0.0)).astype(_F32)
     flats = np.nonzero(s == 0)[0]                                 # :92
     for idx in flats[::-1]:                                       # :94-107, right to left, in place
         nxt = min(int(idx) + 1, s.shape[0] - 1)
