@@ -321,6 +321,7 @@ def main():
             "K2-K4_music(evd+scan)": {"us": t_music, "GBs": (ab["evd"] + ab["scan"]) * BATCH / (t_music * 1e-6) / 1e9},
             "K5_peak": {"us": t_peak, "GBs": ab["peak"] * BATCH / (t_peak * 1e-6) / 1e9},
         },
+        "kernels_note": "stand-alone block launches on one stream, HIP events; the timed pipeline fuses K5 into K4",
         "max_angle_error_deg": ang_err,
     }
     if gather_note:
