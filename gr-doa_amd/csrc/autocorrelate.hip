@@ -399,13 +399,12 @@ __global__ void cov_fb_kernel(float2 *out, int nn, long long n_items, float fb_h
     if (e2 != e) p[e2] = nv;
 }
 
-// Waves per CU one launch may occupy (0 = one wave per snapshot, no cap).  8 is enough to saturate
-// HBM (8 x 16 KiB in flight per CU) and leaves half of every CU's wave slots to the EVD / scan
-// kernels of neighbouring batches running on other streams: measured +8 % pipeline throughput at
-// batch 4096 for -0.7 us on the kernel alone.
+// Waves per CU one launch may occupy (0 = one wave per snapshot, no cap); larger launches grid-stride.  16 = one
+// wave per snapshot at the benchmark batch (4096 snapshots on 256 CUs): measured against 8 with the round-1
+// kernels, -0.6 us on the kernel alone (23.2 vs 23.8 us) and -1.2 us per 4-stream pipeline step (25.6 vs 27.1).
 static int cov_waves_per_cu()
 {
-    static int v = [] { const char *e = getenv("DOA_COV_WAVES_PER_CU"); return e ? atoi(e) : 8; }();
+    static int v = [] { const char *e = getenv("DOA_COV_WAVES_PER_CU"); return e ? atoi(e) : 16; }();
     return v;
 }
 
