@@ -223,12 +223,13 @@ template <int N, typename T> struct ChebQ {
 };
 
 // The benchmark shape of K4+K5 as its own lean kernel: P == 256*CH exactly (no bounds predicates),
-// num_max_vals == 1 (the peak pick is "first position whose dB equals the maximum", a 6-step DPP
-// integer minimum), compiled polynomial size == the array size (unconditional scalar loads of the
-// coefficient record).  Nothing generic is compiled in, which keeps it at ~110 VGPRs (4 waves per
-// SIMD) where the general kernel needs 200+.  Items whose maximum of 1/Q is not a finite positive
-// number (a zero, negative or non-finite null spectrum: non-finite input, in practice) take a slow
-// rolled path that follows the general kernel's semantics literally.
+// num_max_vals == 1 (the peak pick is "first position whose dB equals the maximum": compares land in
+// SGPR pairs, the position search is s_ff1 / s_min on the scalar unit), compiled polynomial size == the
+// array size (unconditional scalar loads of the coefficient record).  Nothing generic is compiled in,
+// which keeps it at ~110 VGPRs (4 waves per SIMD) where the general kernel needs 200+.  Items whose
+// minimum of Q is not a finite positive number (a zero, negative or non-finite null spectrum:
+// non-finite input, in practice) take a slow rolled path that follows the general kernel's semantics
+// literally.
 // MULTI: num_max_vals > 1 (the flowgraph's two sources): same arithmetic, the dB values stay in
 // registers and go through the general peak_pick.
 template <int N, int CH, typename T, bool MULTI = false>
