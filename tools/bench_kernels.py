@@ -102,6 +102,27 @@ if "mpipe" in args.stages:
     res["mpipe_streams"] = S
     res["mpipe_us"] = (min(ts), sorted(ts)[2])
     res["mpipe_snapshots_per_s"] = B / min(ts) * 1e6
+if "mroot" in args.stages:
+    # configs[2]: autocorrelate -> rootMUSIC_linear_array, steps alternating over several streams
+    import time
+    S = args.streams
+    sts = [torch.cuda.Stream() for _ in range(S)]
+    covs = [doa.autocorrelate(N, K, OVL, FB) for _ in range(S)]
+    roots = [doa.rootMUSIC_linear_array(0.5, M, N) for _ in range(S)]
+    angs = [torch.empty((B, M), dtype=torch.float32, device="cuda") for _ in range(nb)]
+    def run_root(n):
+        for i in range(n):
+            k = i % S
+            covs[k].work_dev(B, ptrs[i % nb], cov[i % nb].data_ptr(), sts[k])
+            roots[k].work_dev(B, cov[i % nb].data_ptr(), angs[i % nb].data_ptr(), sts[k])
+    run_root(2 * S * nb); torch.cuda.synchronize()
+    ts = []
+    for r in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); run_root(args.reps); torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / args.reps * 1e6)
+    res["mroot_streams"] = S
+    res["mroot_us"] = (min(ts), sorted(ts)[2])
+    res["mroot_snapshots_per_s"] = B / min(ts) * 1e6
 if "host" in args.stages:
     # the host-pointer entry point (PCIe-inclusive): pageable vs page-locked caller buffers,
     # angles only vs spectrum returned as well; also the GNU Radio-sized call (8 items)
