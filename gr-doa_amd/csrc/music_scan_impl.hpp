@@ -367,6 +367,79 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
     }
 }
 
+// Long spectra (P % 4 == 0, any length): one wave per item, 4 consecutive angles per lane per 256-angle
+// chunk, chunks in a ROLLED loop and Q evaluated twice (minimum first, then dB and store), so that nothing
+// of the row lives in registers: ~100 VGPRs where the unrolled CH = 16 kernel needs 430-511 (one wave per
+// SIMD).  The table is re-read from L2 per chunk; coefficients sit in SGPRs.  Same arithmetic as the lean
+// kernel (one transcendental per angle); rows whose minimum of Q is not a finite positive number follow the
+// general semantics (db_from_ratio) in a third form of the second pass.
+template <int N, typename T>
+__global__ __launch_bounds__(256) void music_scan_stream_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
+                                                                float *__restrict__ spec, int P, int n_items, int n_ant)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
+    const int n_waves = gridDim.x * (blockDim.x / kWave);
+    const int rec = 2 * n_ant;
+    const int n_chunks = (P + 255) / 256;
+    for (int item = wave; item < n_items; item += n_waves) {
+        T c[2 * N];
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) c[k] = (k < rec - 1) ? coef[(size_t)item * rec + k] : (T)0;
+        auto q4 = [&](int j, float (&q)[4]) -> bool {
+            const int i0 = 4 * lane + 256 * j;
+            const bool live = i0 < P;
+            if (live) {
+                const T *zp = ztab + 2 * (size_t)i0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) q[e] = (float)null_spectrum<N, T>(c, zp[2 * e], zp[2 * e + 1]);
+            }
+            return live;
+        };
+        float mn = INFINITY;
+#pragma unroll 1
+        for (int j = 0; j < n_chunks; j++) {
+            float q[4];
+            if (q4(j, q)) mn = fminf(fminf(mn, fminf(q[0], q[1])), fminf(q[2], q[3]));
+        }
+        mn = wave_allreduce_min(mn);
+        float *row = spec + (size_t)item * P;
+        if ((mn > 0.0f) && (mn < INFINITY)) {
+            const float inv_mn = __builtin_amdgcn_rcpf(mn) * 0.99999976158142f;
+#pragma unroll 1
+            for (int j = 0; j < n_chunks; j++) {
+                float q[4];
+                if (q4(j, q)) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) q[e] = fmaf(-3.0102999566398120f, __log2f(fmaxf(q[e] * inv_mn, 1.0f)), 0.0f);
+                    store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(q[0], q[1], q[2], q[3]));
+                }
+            }
+        } else {
+            float mx = -INFINITY;
+#pragma unroll 1
+            for (int j = 0; j < n_chunks; j++) {
+                float q[4];
+                if (q4(j, q)) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_amdgcn_rcpf(q[e]));
+                }
+            }
+            mx = wave_allreduce_max(mx);
+            const float inv_mx = __builtin_amdgcn_rcpf(mx);
+#pragma unroll 1
+            for (int j = 0; j < n_chunks; j++) {
+                float q[4];
+                if (q4(j, q)) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) q[e] = db_from_ratio(__builtin_amdgcn_rcpf(q[e]), mx, inv_mx);
+                    store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(q[0], q[1], q[2], q[3]));
+                }
+            }
+        }
+    }
+}
+
 // Any P: one wave per item, one angle per lane per step, two passes (max, then write).
 template <int N, typename T>
 __global__ __launch_bounds__(256) void music_scan_generic_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
@@ -451,6 +524,17 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
         }
 #undef DOA_LEAN_LAUNCH
         return true;
+    }
+    // long spectra without diagnostics and without a fused peak pick: the streaming two-pass kernel
+    static const int stream_on = [] { const char *e = getenv("DOA_SCAN_STREAM"); return e ? atoi(e) : 1; }();
+    // P > 2048 in double: peak_pick<16> on a register-resident row makes the fused kernel a 511-VGPR, one-wave-
+    // per-SIMD kernel (135 us per 4096 items at N = 16); the streaming scan (~30 us) followed by the stand-alone
+    // find_local_max kernel (~47 us) is faster, so the peak pick is left to the caller there (returns false).
+    if (stream_on && aligned && P > 2048 && sizeof(T) == 8 && !q) {
+        int sb = (n_items + waves_per_block - 1) / waves_per_block;
+        if (sb > cu_count() * 16 / waves_per_block) sb = cu_count() * 16 / waves_per_block;
+        hipLaunchKernelGGL((music_scan_stream_kernel<N, T>), dim3(sb), block, 0, st, co, z, sp, P, n_items, n_ant);
+        return false;
     }
     if (aligned && P <= 4096) {
         constexpr bool ZBIG = (sizeof(T) == 4);          // float tables fit the register file up to P = 4096
