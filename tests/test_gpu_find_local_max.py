@@ -113,3 +113,15 @@ def test_full_batch_property():
     assert all(np.isin(o0[i], v[i]).all() for i in range(0, 4096, 97))
     r0, r1 = oracle.find_local_max(v[:256], 3, 1024, 0.0, 180.0)
     assert np.array_equal(o0[:256], r0) and np.array_equal(o1[:256], r1)
+
+
+def test_fuzz_both_kernels_against_oracle():
+    # tools/fuzz_find_local_max.py: random lengths 3..5000 (register kernel, streaming mask kernel, serial kernel),
+    # num_max_vals 1..16, smooth / quantised / constant / spiky vectors with NaN and +-inf sprinkled in
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_find_local_max.py")
+    spec = importlib.util.spec_from_file_location("fuzz_find_local_max", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(n_cases=250, seed=11, verbose=False) == 0
