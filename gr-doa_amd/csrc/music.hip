@@ -557,6 +557,20 @@ __global__ __launch_bounds__(64) void music_evd_group_kernel(const float2 *__res
 // Padding (N < 16): zero rows/columns -- never rotated (pivot 0 -> identity), they only travel; a
 // 16-bit mask that takes the same permutation tells the epilogue which slots are padding.
 // ---------------------------------------------------------------------------------------------
+// DPP move of a float or double: lanes whose source lies outside their 16-lane row, or whose bank is masked
+// off, receive `old`
+template <int CTRL, int BANK_MASK> __device__ __forceinline__ float dpp_row_shift(float old, float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, BANK_MASK, false));
+}
+template <int CTRL, int BANK_MASK> __device__ __forceinline__ double dpp_row_shift(double old, double v)
+{
+    const long long o = __double_as_longlong(old), x = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(o & 0xFFFFFFFFll), (int)(x & 0xFFFFFFFFll), CTRL, 0xF, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(x >> 32), CTRL, 0xF, BANK_MASK, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 template <typename T> __device__ __forceinline__ T wave_sum_t(T v)
 {
 #pragma unroll
@@ -588,7 +602,9 @@ __global__ __launch_bounds__(64) void music_evd_block16_kernel(const float2 *__r
     constexpr int G = 16;
     __shared__ T sVr[G * G], sVi[G * G], sLam[G];
     const int lane = threadIdx.x & (kWave - 1);
-    const int a = lane >> 3, b = lane & 7;
+    // lane = 16 (a >> 1) + 2 b + (a & 1): the two block rows that share a 16-lane DPP row are interleaved, so that
+    // "column block b -> b +- 1" is a DPP row shift by 2 lanes whose out-of-row lanes are exactly b = 0 / b = 7
+    const int a = ((lane >> 4) << 1) | (lane & 1), b = (lane & 15) >> 1;
     const int item = blockIdx.x;                         // grid = n_items
     const float2 *Ri = R + (size_t)item * (N * N);
     T xr[2][2], xi[2][2], vr[2][2], vi[2][2];
@@ -608,9 +624,9 @@ __global__ __launch_bounds__(64) void music_evd_block16_kernel(const float2 *__r
             vr[i][j] = (row == col) ? (T)1 : (T)0; vi[i][j] = 0;
         }
     unsigned pad = (N >= G) ? 0u : (((1u << G) - 1u) & ~((1u << N) - 1u));      // bit k: physical slot k is padding
-    const int src_a = 9 * a, src_b = 9 * b;              // diagonal lanes (a,a) and (b,b)
-    const int ln_l = (lane + kWave - 1) & (kWave - 1), ln_r = (lane + 1) & (kWave - 1);
-    const int ln_u = (lane + kWave - 8) & (kWave - 1), ln_d = (lane + 8) & (kWave - 1);
+    auto lane_of = [](int aa, int bb) { return 16 * (aa >> 1) + 2 * bb + (aa & 1); };
+    const int src_a = lane_of(a, a), src_b = lane_of(b, b);                 // diagonal lanes (a,a) and (b,b)
+    const int ln_u = lane_of((a + 7) & 7, b), ln_d = lane_of((a + 1) & 7, b); // block rows a-1 / a+1 (ends unused)
     const int max_sweeps = Real<T>::max_sweeps + G;
     for (int sweep = 0; sweep < max_sweeps; sweep++) {
         T off = 0, dn = 0;
@@ -671,15 +687,18 @@ __global__ __launch_bounds__(64) void music_evd_block16_kernel(const float2 *__r
                 xi[1][j] = ca * q_i + (sar * p_i - sai * p_r);
             }
             // caterpillar step, columns (A and V): slot 0 <- left neighbour, slot 1 <- right neighbour
+            // DPP row shifts by 2 lanes (one block column): lanes without a source (b = 0 for the shift right,
+            // b = 7 for the shift left) keep `old`, which is exactly the boundary rule -- no selects.  b = 1 takes
+            // slot 1 of b = 0 instead of slot 0: a second shift restricted to DPP bank 0 (lanes 0-3 of the row).
             auto move_cols = [&](T (&m)[2][2]) {
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
-                    const T to_right = (b == 0) ? m[i][1] : m[i][0];
-                    const T from_left = lane_fetch<T>(to_right, ln_l);
-                    const T from_right = lane_fetch<T>(m[i][1], ln_r);
-                    const T keep = m[i][0];
-                    m[i][0] = (b == 0) ? keep : from_left;
-                    m[i][1] = (b == 7) ? keep : from_right;
+                    const T s0 = m[i][0], s1 = m[i][1];
+                    T n0 = dpp_row_shift<0x112, 0xF>(s0, s0);              // row_shr:2, old = own slot 0 (b = 0 keeps it)
+                    n0 = dpp_row_shift<0x112, 0x1>(n0, s1);                // bank 0 only: b = 1 <- slot 1 of b = 0
+                    const T n1 = dpp_row_shift<0x102, 0xF>(s0, s1);        // row_shl:2, old = own slot 0 (b = 7 takes it)
+                    m[i][0] = n0;
+                    m[i][1] = n1;
                 }
             };
             move_cols(xr); move_cols(xi); move_cols(vr); move_cols(vi);
