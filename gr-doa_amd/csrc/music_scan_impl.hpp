@@ -368,8 +368,8 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
 }
 
 // Long spectra (P % 4 == 0, any length): one wave per item, 4 consecutive angles per lane per 256-angle
-// chunk, chunks in a ROLLED loop and Q evaluated twice (minimum first, then dB and store), so that nothing
-// of the row lives in registers: ~100 VGPRs where the unrolled CH = 16 kernel needs 430-511 (one wave per
+// chunk, chunks in a ROLLED loop, Q parked as float in the output row between the two passes (minimum first,
+// then dB in place), so that nothing of the row lives in registers: ~100 VGPRs where the unrolled CH = 16 kernel needs 430-511 (one wave per
 // SIMD).  The table is re-read from L2 per chunk; coefficients sit in SGPRs.  Same arithmetic as the lean
 // kernel (one transcendental per angle); rows whose minimum of Q is not a finite positive number follow the
 // general semantics (db_from_ratio) in a third form of the second pass.
@@ -396,20 +396,32 @@ __global__ __launch_bounds__(256) void music_scan_stream_kernel(const T *__restr
             }
             return live;
         };
+        // pass 1: Q as float parked in the output row itself (this lane re-reads exactly the addresses it wrote),
+        // and its minimum; pass 2 turns the row into dB in place -- the (N-1)-step double Horner runs once per angle
+        float *row = spec + (size_t)item * P;
         float mn = INFINITY;
 #pragma unroll 1
         for (int j = 0; j < n_chunks; j++) {
             float q[4];
-            if (q4(j, q)) mn = fminf(fminf(mn, fminf(q[0], q[1])), fminf(q[2], q[3]));
+            if (q4(j, q)) {
+                mn = fminf(fminf(mn, fminf(q[0], q[1])), fminf(q[2], q[3]));
+                *reinterpret_cast<float4 *>(row + 4 * lane + 256 * j) = make_float4(q[0], q[1], q[2], q[3]);
+            }
         }
         mn = wave_allreduce_min(mn);
-        float *row = spec + (size_t)item * P;
+        auto reload = [&](int j, float (&q)[4]) -> bool {
+            const int i0 = 4 * lane + 256 * j;
+            if (i0 >= P) return false;
+            const float4 t = *reinterpret_cast<const float4 *>(row + i0);
+            q[0] = t.x; q[1] = t.y; q[2] = t.z; q[3] = t.w;
+            return true;
+        };
         if ((mn > 0.0f) && (mn < INFINITY)) {
             const float inv_mn = __builtin_amdgcn_rcpf(mn) * 0.99999976158142f;
 #pragma unroll 1
             for (int j = 0; j < n_chunks; j++) {
                 float q[4];
-                if (q4(j, q)) {
+                if (reload(j, q)) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) q[e] = fmaf(-3.0102999566398120f, __log2f(fmaxf(q[e] * inv_mn, 1.0f)), 0.0f);
                     store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(q[0], q[1], q[2], q[3]));
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(256) void music_scan_stream_kernel(const T *__restr
 #pragma unroll 1
             for (int j = 0; j < n_chunks; j++) {
                 float q[4];
-                if (q4(j, q)) {
+                if (reload(j, q)) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_amdgcn_rcpf(q[e]));
                 }
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(256) void music_scan_stream_kernel(const T *__restr
 #pragma unroll 1
             for (int j = 0; j < n_chunks; j++) {
                 float q[4];
-                if (q4(j, q)) {
+                if (reload(j, q)) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) q[e] = db_from_ratio(__builtin_amdgcn_rcpf(q[e]), mx, inv_mx);
                     store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(q[0], q[1], q[2], q[3]));
