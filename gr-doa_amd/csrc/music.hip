@@ -781,6 +781,225 @@ __global__ __launch_bounds__(64) void music_evd_block16_kernel(const float2 *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 4 < N <= 8: the same block scheme on an 8 x 8 problem -- 16 lanes per item (lane 4 b + a of its 16-lane DPP
+// row holds the 2 x 2 blocks A[2a..][2b..], V[..]), one item per DPP row, four items per wave.  Column block
+// moves are DPP row shifts by 4 lanes (out-of-row lanes = the end blocks, which keep `old`), row block moves
+// stay inside a quad (quad_perm); only the rotation parameters travel through ds_bpermute.  7 rounds per
+// sweep.  ~75 VGPRs instead of the 280 of the 8-lanes-per-item row layout, and twice as many waves for the
+// same batch.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned caterpillar_mask8(unsigned m)
+{
+    // new[0]=old[0], new[2]=old[1], new[4]=old[2], new[6]=old[4], new[1]=old[3], new[3]=old[5], new[5]=old[7], new[7]=old[6]
+    return (m & 1u) | (((m >> 1) & 1u) << 2) | (((m >> 2) & 1u) << 4) | (((m >> 4) & 1u) << 6) | (((m >> 3) & 1u) << 1) |
+           (((m >> 5) & 1u) << 3) | (((m >> 7) & 1u) << 5) | (((m >> 6) & 1u) << 7);
+}
+
+template <int CTRL> __device__ __forceinline__ float dpp_quad(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_quad(double v)
+{
+    const long long x = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(x & 0xFFFFFFFFll), (int)(x & 0xFFFFFFFFll), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(x >> 32), (int)(x >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <typename T, bool LEAN>
+__global__ __launch_bounds__(64) void music_evd_block8_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
+                                                              double *__restrict__ coef_d, float2 *__restrict__ pn_out,
+                                                              int n_items, int N, int M,
+                                                              const float2 *__restrict__ pilot, float2 *__restrict__ cal_out)
+{
+    constexpr int G = 8;
+    __shared__ T sVr[4][G * G], sVi[4][G * G], sLam[4][G];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int grp = lane >> 4, q = lane & 15, base = lane - q;
+    const int a = q & 3, b = q >> 2;
+    int item = blockIdx.x * 4 + grp;
+    const bool real_item = item < n_items;
+    if (!real_item) item = n_items - 1;                  // idle groups shadow the last item (no stores)
+    const float2 *Ri = R + (size_t)item * (N * N);
+    T xr[2][2], xi[2][2], vr[2][2], vi[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int row = 2 * a + i, col = 2 * b + j;
+            T re = 0, im = 0;
+            if (row < N && col < N) {
+                const float2 x = (row <= col) ? Ri[row + col * N] : Ri[col + row * N];      // upper triangle only
+                re = (T)x.x;
+                im = (row == col) ? (T)0 : ((row < col) ? (T)x.y : -(T)x.y);
+            }
+            xr[i][j] = re; xi[i][j] = im;
+            vr[i][j] = (row == col) ? (T)1 : (T)0; vi[i][j] = 0;
+        }
+    unsigned pad = (N >= G) ? 0u : (((1u << G) - 1u) & ~((1u << N) - 1u));
+    const int src_a = base + 5 * a, src_b = base + 5 * b;            // diagonal lanes (a,a) and (b,b): q = 4 k + k
+    const int max_sweeps = Real<T>::max_sweeps + G;
+    bool active = true;
+    for (int sweep = 0; sweep < max_sweeps; sweep++) {
+        T off = 0, dn = 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const T m = xr[i][j] * xr[i][j] + xi[i][j] * xi[i][j];
+                if (a == b && i == j) dn += m; else off += m;
+            }
+        off = group_sum<16, T>(off, lane);
+        dn = group_sum<16, T>(dn, lane);
+        active = active && (off > Real<T>::tol * dn) && (off > Real<T>::tiny);
+        if (!__any(active)) break;
+#pragma unroll 1
+        for (int round = 0; round < G - 1; round++) {
+            const T d_p = xr[0][0], d_q = xr[1][1], pr = xr[0][1], pi = xi[0][1];
+            const T g2 = pr * pr + pi * pi;
+            const bool live = active && (g2 > Real<T>::tiny);
+            const T inv_g = Real<T>::rsqrt(live ? g2 : (T)1);
+            const T phr = pr * inv_g, phi = pi * inv_g;
+            T tau = (d_q - d_p) * (T)0.5 * inv_g;
+            tau = fmin(fmax(tau, -Real<T>::tau_max), Real<T>::tau_max);
+            const T x1 = fma(tau, tau, (T)1);
+            const T rt = x1 * Real<T>::rsqrt(x1);
+            const T h = fabs(tau) + rt;
+            const T w = Real<T>::rsqrt(fma(h, h, (T)1));
+            const T c_mine = live ? h * w : (T)1;
+            const T s_mine = live ? copysign(w, tau) : (T)0;
+            const T sr_mine = s_mine * phr, si_mine = s_mine * phi;              // sigma = J[p][q]
+            const T ca = lane_fetch<T>(c_mine, src_a), sar = lane_fetch<T>(sr_mine, src_a), sai = lane_fetch<T>(si_mine, src_a);
+            const T cb = lane_fetch<T>(c_mine, src_b), sbr = lane_fetch<T>(sr_mine, src_b), sbi = lane_fetch<T>(si_mine, src_b);
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                {
+                    const T p_r = xr[i][0], p_i = xi[i][0], q_r = xr[i][1], q_i = xi[i][1];
+                    xr[i][0] = cb * p_r - (sbr * q_r + sbi * q_i);
+                    xi[i][0] = cb * p_i - (sbr * q_i - sbi * q_r);
+                    xr[i][1] = cb * q_r + (sbr * p_r - sbi * p_i);
+                    xi[i][1] = cb * q_i + (sbr * p_i + sbi * p_r);
+                }
+                {
+                    const T p_r = vr[i][0], p_i = vi[i][0], q_r = vr[i][1], q_i = vi[i][1];
+                    vr[i][0] = cb * p_r - (sbr * q_r + sbi * q_i);
+                    vi[i][0] = cb * p_i - (sbr * q_i - sbi * q_r);
+                    vr[i][1] = cb * q_r + (sbr * p_r - sbi * p_i);
+                    vi[i][1] = cb * q_i + (sbr * p_i + sbi * p_r);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const T p_r = xr[0][j], p_i = xi[0][j], q_r = xr[1][j], q_i = xi[1][j];
+                xr[0][j] = ca * p_r - (sar * q_r - sai * q_i);
+                xi[0][j] = ca * p_i - (sar * q_i + sai * q_r);
+                xr[1][j] = ca * q_r + (sar * p_r + sai * p_i);
+                xi[1][j] = ca * q_i + (sar * p_i - sai * p_r);
+            }
+            // caterpillar step, columns: DPP row shifts by 4 lanes (one block column); b = 0 / b = 3 keep `old`
+            auto move_cols = [&](T (&m)[2][2]) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const T s0 = m[i][0], s1 = m[i][1];
+                    T n0 = dpp_row_shift<0x114, 0xF>(s0, s0);              // row_shr:4
+                    n0 = dpp_row_shift<0x114, 0x2>(n0, s1);                // bank 1 (b = 1) <- slot 1 of b = 0
+                    const T n1 = dpp_row_shift<0x104, 0xF>(s0, s1);        // row_shl:4, b = 3 takes its own slot 0
+                    m[i][0] = n0;
+                    m[i][1] = n1;
+                }
+            };
+            move_cols(xr); move_cols(xi); move_cols(vr); move_cols(vi);
+            // rows (A only): inside the quad a = 0..3
+            auto move_rows = [&](T (&m)[2][2]) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const T to_down = (a == 0) ? m[1][j] : m[0][j];
+                    const T from_up = dpp_quad<0x90>(to_down);             // quad_perm [0,0,1,2]: lane a <- a-1
+                    const T from_down = dpp_quad<0xF9>(m[1][j]);           // quad_perm [1,2,3,3]: lane a <- a+1
+                    const T keep = m[0][j];
+                    m[0][j] = (a == 0) ? keep : from_up;
+                    m[1][j] = (a == 3) ? keep : from_down;
+                }
+            };
+            move_rows(xr); move_rows(xi);
+            pad = caterpillar_mask8(pad);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            sVr[grp][(2 * a + i) * G + 2 * b + j] = vr[i][j];
+            sVi[grp][(2 * a + i) * G + 2 * b + j] = vi[i][j];
+        }
+    if (a == b) {
+        sLam[grp][2 * a] = ((pad >> (2 * a)) & 1u) ? (T)1e30 : xr[0][0];
+        sLam[grp][2 * a + 1] = ((pad >> (2 * a + 1)) & 1u) ? (T)1e30 : xr[1][1];
+    }
+    __syncthreads();
+    if constexpr (LEAN) {
+        bool is_noise = false;
+        if (q < G) {
+            const T lam = sLam[grp][q];
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                const T lj = sLam[grp][j];
+                rank += ((lj < lam) || (lj == lam && j < q)) ? 1 : 0;
+            }
+            is_noise = !((pad >> q) & 1u) && (rank < N - M);
+        }
+        const unsigned sel = (unsigned)((__ballot(is_noise) >> base) & 0xFFull);
+        // u_l = sum_r sum_{i in noise} V[r+l][i] conj(V[r][i]):  lane q = 2 l + c takes the rows r = c (mod 2)
+        const int l = q >> 1, c2 = q & 1;
+        T tr = 0, ti = 0;
+        if (l < N) {
+            for (int r = c2; r + l < N; r += 2) {
+                const T *ur = sVr[grp] + (r + l) * G, *ui = sVi[grp] + (r + l) * G, *wr = sVr[grp] + r * G, *wi = sVi[grp] + r * G;
+#pragma unroll
+                for (int i = 0; i < G; i++)
+                    if ((sel >> i) & 1u) {
+                        tr = fma(ur[i], wr[i], fma(ui[i], wi[i], tr));
+                        ti = fma(ui[i], wr[i], fma(-ur[i], wi[i], ti));
+                    }
+            }
+        }
+        tr += lane_fetch<T>(tr, lane ^ 1); ti += lane_fetch<T>(ti, lane ^ 1);
+        if (c2 == 0 && l < N && real_item) {
+            float *co = coef ? coef + (size_t)item * (2 * N) : nullptr;
+            double *cd = coef_d ? coef_d + (size_t)item * (2 * N) : nullptr;
+            if (l == 0) {
+                if (co) { co[0] = (float)tr; co[2 * N - 1] = 0.f; }
+                if (cd) { cd[0] = (double)tr; cd[2 * N - 1] = 0.0; }
+            } else {
+                if (co) { co[2 * l - 1] = (float)tr; co[2 * l] = (float)ti; }
+                if (cd) { cd[2 * l - 1] = (double)tr; cd[2 * l] = (double)ti; }
+            }
+        }
+    } else if (q < G) {
+        T er[G], ei[G];
+#pragma unroll
+        for (int k = 0; k < G; k++) { er[k] = sVr[grp][q * G + k]; ei[k] = sVi[grp][q * G + k]; }
+        evd_group_epilogue<G, T>(er, ei, sLam[grp][q], !((pad >> q) & 1u), q, base, lane, item, real_item, N, M, coef, coef_d,
+                                 pn_out, pilot, cal_out);
+    }
+}
+
+template <typename T>
+static void launch_evd_block8(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
+                              hipStream_t st, const void *d_pilot = nullptr, void *d_cal = nullptr)
+{
+    const dim3 grid((n_items + 3) / 4), block(64);
+    if (!d_pn && !d_cal)
+        hipLaunchKernelGGL((music_evd_block8_kernel<T, true>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,
+                           (double *)d_coef_d, nullptr, n_items, N, M, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((music_evd_block8_kernel<T, false>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,
+                           (double *)d_coef_d, (float2 *)d_pn, n_items, N, M, (const float2 *)d_pilot, (float2 *)d_cal);
+}
+
 template <typename T>
 static void launch_evd_block16(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
                                hipStream_t st, const void *d_pilot = nullptr, void *d_cal = nullptr)
@@ -843,12 +1062,20 @@ int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, v
     static const int force_group = [] { const char *e = getenv("DOA_EVD_KERNEL"); return e ? atoi(e) : 0; }();
     const bool f32 = (evd_bits == 32);
     static const int block16 = [] { const char *e = getenv("DOA_EVD16_BLOCK"); return e ? atoi(e) : 1; }();
+    // 4 < N <= 8: the 16-lanes-per-item block kernel is the faster one on its own (46 vs 63 us per 4096 items at N = 8)
+    // but costs 10 % of the 4-stream pipeline throughput (80 vs 72 us per step): its data movement runs on the vector
+    // pipe (DPP), which the N = 8 covariance kernel also needs, where the row-per-lane kernel uses the LDS pipe and only
+    // half of the SIMDs.  Throughput wins the default; DOA_EVD8_BLOCK=1 selects the low-latency kernel.
+    static const int block8 = [] { const char *e = getenv("DOA_EVD8_BLOCK"); return e ? atoi(e) : 0; }();
     if (N > 8 && block16) {
         if (f32) launch_evd_block16<float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
         else launch_evd_block16<double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
     } else if (N > 8) {
         if (f32) launch_evd_group<16, float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
         else launch_evd_group<16, double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
+    } else if (N > 4 && block8) {
+        if (f32) launch_evd_block8<float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
+        else launch_evd_block8<double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
     } else if (N > 4) {
         if (f32) launch_evd_group<8, float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
         else launch_evd_group<8, double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
