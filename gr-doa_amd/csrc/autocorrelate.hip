@@ -399,13 +399,15 @@ __global__ void cov_fb_kernel(float2 *out, int nn, long long n_items, float fb_h
     if (e2 != e) p[e2] = nv;
 }
 
-// Waves per CU one launch may occupy (0 = one wave per snapshot, no cap); larger launches grid-stride.  16 = one
-// wave per snapshot at the benchmark batch (4096 snapshots on 256 CUs): measured against 8 with the round-1
-// kernels, -0.6 us on the kernel alone (23.2 vs 23.8 us) and -1.2 us per 4-stream pipeline step (25.6 vs 27.1).
-static int cov_waves_per_cu()
+// Waves per CU one launch may occupy (0 = one wave per snapshot, no cap); larger launches grid-stride.  At N = 4,
+// 16 (= one wave per snapshot at the benchmark batch: 4096 snapshots on 256 CUs) measured against 8 with the round-1
+// kernels: -0.6 us on the kernel alone (23.2 vs 23.8 us) and -1.2 us per 4-stream pipeline step (25.6 vs 27.1).
+static int cov_waves_per_cu(int n_ch)
 {
-    static int v = [] { const char *e = getenv("DOA_COV_WAVES_PER_CU"); return e ? atoi(e) : 16; }();
-    return v;
+    // N <= 4: one wave per snapshot at the benchmark batch; wider arrays hold 2-4x the registers per wave and measured
+    // better with 8 (N = 6: 54.4 vs 57.3 us, 4-stream step 56.8 vs 63.0 us)
+    static int v = [] { const char *e = getenv("DOA_COV_WAVES_PER_CU"); return e ? atoi(e) : -1; }();
+    return v >= 0 ? v : (n_ch <= 4 ? 16 : 8);
 }
 
 // the read-once two-kernel path (see cov_piece_kernel)
@@ -413,8 +415,8 @@ template <int TN> static void launch_pieces(const CovArgs &g, hipStream_t st)
 {
     const int waves_per_block = 4;
     int blocks = (g.n_steps + waves_per_block - 1) / waves_per_block;
-    if (cov_waves_per_cu() > 0) {
-        const int cap = cu_count() * cov_waves_per_cu() / waves_per_block;
+    if (cov_waves_per_cu(TN) > 0) {
+        const int cap = cu_count() * cov_waves_per_cu(TN) / waves_per_block;
         if (blocks > cap) blocks = cap;
     }
     constexpr int UN = (TN <= 4) ? 4 : ((TN <= 6) ? 2 : 1);
@@ -428,8 +430,8 @@ template <int TN> static void launch_wave(const CovArgs &g, bool vec2, hipStream
     if (g.pieces) { launch_pieces<TN>(g, st); return; }
     const int waves_per_block = 4;
     int blocks = (g.n_out + waves_per_block - 1) / waves_per_block;
-    if (cov_waves_per_cu() > 0) {
-        const int cap = cu_count() * cov_waves_per_cu() / waves_per_block;
+    if (cov_waves_per_cu(TN) > 0) {
+        const int cap = cu_count() * cov_waves_per_cu(TN) / waves_per_block;
         if (blocks > cap) blocks = cap;
     }
     dim3 grid(blocks), block(waves_per_block * kWave);
