@@ -320,12 +320,35 @@ template <int G, typename T> __device__ __forceinline__ T group_sum(T v, int lan
     return v;
 }
 
+// G == 4: a group is a DPP quad, so every cross-lane fetch of the round is a quad_perm with a compile-time pattern
+// (a few cycles on the vector pipe instead of a ~100-cycle ds_bpermute round trip -- this kernel is a pure latency chain)
+template <int PATTERN> __device__ __forceinline__ float quad_fetch(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), PATTERN, 0xF, 0xF, false));
+}
+template <int PATTERN> __device__ __forceinline__ double quad_fetch(double v)
+{
+    const long long x = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(x & 0xFFFFFFFFll), (int)(x & 0xFFFFFFFFll), PATTERN, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(x >> 32), (int)(x >> 32), PATTERN, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int quad_pattern(int s0, int s1, int s2, int s3) { return s0 | (s1 << 2) | (s2 << 4) | (s3 << 6); }
+// partner of quad lane r in round t of the 4-player tournament: t=0: 0<->3, 1<->2; t=1: 0<->2, 1<->3; t=2: 0<->1, 2<->3
+constexpr int quad_partner(int t, int r) { return (r == 3) ? t : ((r == t) ? 3 : (2 * t - r + 6) % 3); }
+constexpr int quad_lower(int t, int r) { return r < quad_partner(t, r) ? r : quad_partner(t, r); }
+
 template <int G, typename T, int ROUND>
 __device__ __forceinline__ void jacobi_round(T (&ar)[G], T (&ai)[G], T (&vr)[G], T (&vi)[G], int r, int base, bool active)
 {
     using TT = Tournament<G>;
     // partner of lane r in this round
     const int partner = (r == G - 1) ? ROUND : ((r == ROUND) ? G - 1 : (2 * ROUND - r + 2 * (G - 1)) % (G - 1));
+    constexpr int RT = (G == 4) ? ROUND : 0;
+    constexpr int PAT_PARTNER = quad_pattern(quad_partner(RT, 0), quad_partner(RT, 1), quad_partner(RT, 2), quad_partner(RT, 3));
+    constexpr int PAT_LOWER = quad_pattern(quad_lower(RT, 0), quad_lower(RT, 1), quad_lower(RT, 2), quad_lower(RT, 3));
+    auto from_partner = [&](T v) { if constexpr (G == 4) return quad_fetch<PAT_PARTNER>(v); else return lane_fetch<T>(v, base + partner); };
+    auto from_lower = [&](T v, int lo_lane) { if constexpr (G == 4) return quad_fetch<PAT_LOWER>(v); else return lane_fetch<T>(v, base + lo_lane); };
     // own diagonal, partner diagonal, pivot element A[r][partner]
     T d_own = 0, xr = 0, xi = 0;
 #pragma unroll
@@ -334,7 +357,7 @@ __device__ __forceinline__ void jacobi_round(T (&ar)[G], T (&ai)[G], T (&vr)[G],
         xr = (k == partner) ? ar[k] : xr;
         xi = (k == partner) ? ai[k] : xi;
     }
-    const T d_oth = lane_fetch<T>(d_own, base + partner);
+    const T d_oth = from_partner(d_own);
     const T g2 = xr * xr + xi * xi;
     const bool live = active && (g2 > Real<T>::tiny);
     const T inv_g = Real<T>::rsqrt(live ? g2 : (T)1);
@@ -351,16 +374,22 @@ __device__ __forceinline__ void jacobi_round(T (&ar)[G], T (&ai)[G], T (&vr)[G],
     const T c_mine = live ? h * w : (T)1;
     const T s_mine = live ? copysign(w, tau) : (T)0;
     const int lo = (r < partner) ? r : partner;
-    const T c = lane_fetch<T>(c_mine, base + lo);
-    const T slr = lane_fetch<T>(s_mine * phr, base + lo), sli = lane_fetch<T>(s_mine * phi, base + lo);   // sigma = J[lo][hi]
+    const T c = from_lower(c_mine, lo);
+    const T slr = from_lower(s_mine * phr, lo), sli = from_lower(s_mine * phi, lo);   // sigma = J[lo][hi]
     const T sgr = (r == lo) ? slr : -slr, sgi = (r == lo) ? sli : sli;    // J[r][partner]: sigma, or -conj(sigma)
     // column operations A <- A J, V <- V J: canonical (c, sigma) of each pair come from its lower lane
 #pragma unroll
     for (int j = 0; j < G / 2; j++) {
         constexpr int dummy = 0; (void)dummy;
         const int P = TT::p(ROUND, j), Q = TT::q(ROUND, j);
-        const T cj = lane_fetch<T>(c, base + P);
-        const T sr = lane_fetch<T>(sgr, base + P), si = lane_fetch<T>(sgi, base + P);
+        constexpr int P0 = TT::p(RT, 0) & 3, P1 = TT::p(RT, 1) & 3;       // G == 4: the two pairs' lower lanes
+        constexpr int PB0 = quad_pattern(P0, P0, P0, P0), PB1 = quad_pattern(P1, P1, P1, P1);
+        auto bcast = [&](T v) {
+            if constexpr (G == 4) return (j == 0) ? quad_fetch<PB0>(v) : quad_fetch<PB1>(v);
+            else return lane_fetch<T>(v, base + P);
+        };
+        const T cj = bcast(c);
+        const T sr = bcast(sgr), si = bcast(sgi);
         {
             const T pr = ar[P], pi = ai[P], qr = ar[Q], qi = ai[Q];
             ar[P] = cj * pr - (sr * qr + si * qi);
@@ -379,7 +408,7 @@ __device__ __forceinline__ void jacobi_round(T (&ar)[G], T (&ai)[G], T (&vr)[G],
     // row operation A <- J^H A: row_r' = c row_r - sigma_r row_partner (same form on both lanes of a pair)
 #pragma unroll
     for (int k = 0; k < G; k++) {
-        const T orr = lane_fetch<T>(ar[k], base + partner), oi = lane_fetch<T>(ai[k], base + partner);
+        const T orr = from_partner(ar[k]), oi = from_partner(ai[k]);
         const T nr = c * ar[k] - (sgr * orr - sgi * oi);
         const T ni = c * ai[k] - (sgr * oi + sgi * orr);
         ar[k] = nr; ai[k] = ni;
