@@ -419,7 +419,7 @@ template <int TN> static void launch_pieces(const CovArgs &g, hipStream_t st)
         const int cap = cu_count() * cov_waves_per_cu(TN) / waves_per_block;
         if (blocks > cap) blocks = cap;
     }
-    constexpr int UN = (TN <= 4) ? 4 : ((TN <= 6) ? 2 : 1);
+    constexpr int UN = (TN <= 6) ? 4 : 2;
     hipLaunchKernelGGL((cov_piece_kernel<TN, UN, true>), dim3(blocks), dim3(waves_per_block * kWave), 0, st, g);
     const long long total = (long long)g.n_out * g.n_ch * g.n_ch;
     hipLaunchKernelGGL(cov_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g);
@@ -435,8 +435,9 @@ template <int TN> static void launch_wave(const CovArgs &g, bool vec2, hipStream
         if (blocks > cap) blocks = cap;
     }
     dim3 grid(blocks), block(waves_per_block * kWave);
-    // UN*TN 16-byte loads in flight per wave (UN = 1, 2, 8 measured within 3 % of UN = 4 at N = 4)
-    constexpr int UN = (TN <= 4) ? 4 : ((TN <= 6) ? 2 : 1);
+    // UN*TN 16-byte loads in flight per wave (UN = 1, 2, 8 measured within 3 % of UN = 4 at N = 4; N = 6: 44 us with
+    // UN = 4 against 55 with 2; N = 7: 68 us with 2 against 74 with 1)
+    constexpr int UN = (TN <= 6) ? 4 : 2;
     if (!vec2) {
         hipLaunchKernelGGL((cov_wave_kernel<TN, false, 1, false>), grid, block, 0, st, g);
         return;
