@@ -15,7 +15,8 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("name", ["bench_cfg2", "grc_music_sim", "three_ant_fb", "qa_music_aoa23", "five_ant"])
+@pytest.mark.parametrize("name", ["bench_cfg2", "grc_music_sim", "three_ant_fb", "qa_music_aoa23", "five_ant", "bench_cfg4",
+                                  "twelve_ant", "xml_default_p20", "two_ant"])
 def test_pipeline_equals_chained_blocks_and_oracle(name):
     c, x = make_input(name)
     N, M, P, n = c["N"], c["M"], c["P"], c["n"]
@@ -91,7 +92,7 @@ def test_pipeline_rejects_oversized_batch():
         pipe.work_dev(9, [1, 1, 1, 1], 0, 0, 1, 1, None)
 
 
-@pytest.mark.parametrize("name", ["bench_cfg2", "grc_music_sim", "three_ant_fb", "five_ant"])
+@pytest.mark.parametrize("name", ["bench_cfg2", "grc_music_sim", "three_ant_fb", "five_ant", "bench_cfg4", "twelve_ant"])
 def test_pipeline_host_entry_equals_device_entry(name):
     # doa_music_pipeline_work (host buffers, what a GNU Radio hier block would call) against the
     # device-pointer entry point on the same samples: bit for bit, optional outputs optional
