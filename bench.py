@@ -191,7 +191,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DOA_BENCH_FORCE_DIST"):      # the switch rehearses the RCCL code path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -238,6 +238,11 @@ def main():
     torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
+    if dist is not None:
+        # the result gather inside the timed region must not pay RCCL's first-use setup for that collective
+        torch.cuda.synchronize()
+        mine = am[0].reshape(-1).contiguous()
+        dist.all_gather_into_tensor(torch.empty(world * mine.numel(), dtype=mine.dtype, device="cuda"), mine)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
