@@ -1,7 +1,8 @@
 """One-off fuzz of the two find_local_max kernels (wave kernel and one-thread-per-vector kernel) against
 the oracle, bit for bit: random lengths (multiples of 4 and not, up to 5000), num_max_vals 1..16, values
 drawn from smooth / quantised (flat-heavy) / constant / spiky families with NaN and +-inf sprinkled in.
-usage: python tools/fuzz_find_local_max.py [n_cases] [seed]"""
+usage: python tests/fuzz_find_local_max.py [n_cases] [seed]
+(lives under tests/ because it checks against the oracle, which only test code may import)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "gr-doa_amd", "python"), os.path.join(ROOT, "oracle")]

@@ -116,11 +116,11 @@ def test_full_batch_property():
 
 
 def test_fuzz_both_kernels_against_oracle():
-    # tools/fuzz_find_local_max.py: random lengths 3..5000 (register kernel, streaming mask kernel, serial kernel),
+    # tests/fuzz_find_local_max.py: random lengths 3..5000 (register kernel, streaming mask kernel, serial kernel),
     # num_max_vals 1..16, smooth / quantised / constant / spiky vectors with NaN and +-inf sprinkled in
     import importlib.util
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_find_local_max.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_find_local_max.py")
     spec = importlib.util.spec_from_file_location("fuzz_find_local_max", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
