@@ -165,6 +165,47 @@ def cpu_baseline(budget_s=12.0):
             "single_thread_value": rate1}
 
 
+def sharded_check(doa, torch, dist, world, local_rank, per_rank=512, K=1024, ovl=256, theta=(41.0, 117.0)):
+    """doa.distributed.run_sharded over one simulated stream (two fixed sources, overlapping windows, FB averaging):
+    returns what rank 0 reports.  Correctness = every gathered angle pair sits on the two source directions."""
+    n_total, S = world * per_rank, K - ovl
+    dev = torch.device("cuda", local_rank)
+
+    def my_samples(begin, end):                     # this rank's shard only, generated in place
+        src = doa.sim_source(N_ANT, 0.45, list(theta), [0.031, 0.047], None, None, 0.1, seed=99)
+        src.seek(begin)
+        bufs = [torch.empty(end - begin, dtype=torch.complex64, device=dev) for _ in range(N_ANT)]
+        src.work_dev(end - begin, [b.data_ptr() for b in bufs], torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        return bufs
+
+    def compute(bufs, n_local):
+        pipe = doa.music_pipeline(N_ANT, K, ovl, 1, 0.45, 2, P_SPEC, max(n_local, 1))
+        mx = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
+        am = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
+        pipe.work_dev(n_local, [b.data_ptr() for b in bufs], 0, 0, mx.data_ptr(), am.data_ptr(), torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        return am
+
+    t0 = time.perf_counter()
+    angles, shard = doa.distributed.run_sharded(my_samples, n_total, K, ovl, compute, dist=dist)
+    dt = time.perf_counter() - t0
+    a = angles.cpu().numpy()
+    err = float(max(abs(a[:, 0] - max(theta)).max(), abs(a[:, 1] - min(theta)).max()))     # port 1 is sorted descending
+    return {"snapshots": n_total, "ranks": world, "halo_samples": ovl, "shard_samples_rank0": shard.n_samples,
+            "gathered_rows": int(a.shape[0]), "max_angle_error_deg": err, "ok": bool(a.shape[0] == n_total and err <= 1.0),
+            "seconds_incl_generation": dt}
+
+
+def load_launcher():
+    """doa/launch.py by path: importing the `doa` package would load the HIP library into this process."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("doa_launch", os.path.join(ROOT, "gr-doa_amd", "python", "doa", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,10 +219,21 @@ def main():
     ap.add_argument("--no-scan-roofline", action="store_true",
                     help="skip the isolated large-batch scan-kernel measurement (keeps rocprof kernel averages clean)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run", action="store_true", help="with --gpus N > 1: print the N rank commands and exit")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()))
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start one rank per GPU ourselves, BEFORE anything here touches torch or HIP (a
+        # process that has initialised the GPU must never be replaced, and this parent never is: it only waits)
+        launch = load_launcher()
+        argv = [a for a in sys.argv[1:] if a != "--dry-run"]
+        if args.dry_run:
+            for cmd, env in launch.rank_commands(os.path.abspath(__file__), argv, args.gpus):
+                print(" ".join(f"{k}={v}" for k, v in sorted(env.items())), " ".join(cmd))
+            return
+        sys.exit(launch.launch_ranks(os.path.abspath(__file__), argv, args.gpus, timeout=1500))
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,14 +241,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if os.environ.get("DOA_BENCH_SHARE_GPU"):        # rehearsal only: several ranks on one card (with DOA_BENCH_BACKEND=gloo)
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    import doa
     dist = None
     if world > 1 or os.environ.get("DOA_BENCH_FORCE_DIST"):      # the switch rehearses the RCCL code path with one rank
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    import doa
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(doa.launch.free_port())
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+        dist = doa.distributed.init_process_group(os.environ.get("DOA_BENCH_BACKEND", "nccl"),
+                                                  device=torch.device("cuda", local_rank))
+        if world != args.gpus and rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; reporting {world}",
+                  file=sys.stderr)
     doa.set_internal_precision(args.precision)
     n_streams = max(1, args.streams)
     pipes = [doa.music_pipeline(N_ANT, K_SNAP, 0, 0, NORM_SPACING, M_SRC, P_SPEC, BATCH) for _ in range(n_streams)]
@@ -245,22 +304,19 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = doa.distributed.max_over_ranks(elapsed, device="cuda", dist=dist)
 
-    # not part of the path (snapshots are independent: no data-path collective) and therefore outside the timed
-    # region: if the caller wants the per-snapshot results in one place, that is one all_gather of 4 B x batch per rank
-    gather_note = None
+    # Not part of the timed region (snapshots are independent: the path has no data-path collective): the sharded
+    # run itself, product code (doa.distributed.run_sharded) -- ONE stream of world x 512 overlapping windows is cut
+    # into contiguous per-rank shards with their overlap halo, every rank generates only its own samples (seekable
+    # device generator), runs its pipeline, and the per-snapshot angles meet in one RCCL all_gather.
+    sharded = None
     if dist is not None:
         torch.cuda.synchronize()
         try:
-            mine = am[(args.steps - 1) % nbuf].reshape(-1).contiguous()
-            allres = torch.empty(world * mine.numel(), dtype=mine.dtype, device="cuda")
-            dist.all_gather_into_tensor(allres, mine)
-            gather_note = f"all_gather of {mine.numel() * 4} B/rank ok"
-        except Exception as e:                      # never lose the throughput number to the gather
-            gather_note = f"all_gather failed: {e!r}"
+            sharded = sharded_check(doa, torch, dist, world, local_rank)
+        except Exception as e:                      # never lose the throughput number to the check
+            sharded = {"error": repr(e)}
 
     # sanity: the estimates of the last batch must sit on the directions they were generated with
     import numpy as np
@@ -330,8 +386,9 @@ def main():
         "kernels_note": "stand-alone block launches on one stream, HIP events; the timed pipeline fuses K5 into K4",
         "max_angle_error_deg": ang_err,
     }
-    if gather_note:
-        out["result_gather"] = gather_note
+    if dist is not None:
+        out["world_size_seen_by_rccl"] = int(dist.get_world_size())
+        out["sharded_run"] = sharded
     if world == 1 and args.precision == 64 and not args.no_scan_roofline:
         try:
             out["scan_kernel_roofline"] = scan_kernel_roofline(doa, torch, st)
