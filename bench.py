@@ -65,7 +65,7 @@ def scan_kernel_roofline(doa, torch, st, batch=262144, reps=30):
     run = lambda: pipe.work_dev(batch, ptrs, cov.data_ptr(), spec.data_ptr(), mx.data_ptr(), am.data_ptr(), st)
     run()
     torch.cuda.synchronize()
-    os.environ["DOA_PIPE_SKIP"] = "cov,evd"          # read per call by the pipeline (diagnostic switch)
+    pipe.set_stages(cov=False, evd=False, scan=True)   # only the scan launch from here on, on the valid records
     try:
         for _ in range(30):                      # sustained warm-up: the first ~50 launches run measurably slower
             run()
@@ -80,7 +80,7 @@ def scan_kernel_roofline(doa, torch, st, batch=262144, reps=30):
             torch.cuda.synchronize()
             groups.append(e0.elapsed_time(e1) * 1e3 / reps)
     finally:
-        os.environ.pop("DOA_PIPE_SKIP", None)
+        pipe.set_stages()
     us = sorted(groups)[len(groups) // 2]             # median of 5 groups of `reps` back-to-back launches
     nbytes = algorithmic_bytes()["scan_fused"] * batch
     gbs = nbytes / (us * 1e-6) / 1e9

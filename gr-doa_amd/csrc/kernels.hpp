@@ -51,7 +51,8 @@ int launch_find_local_max(const PeakTables &t, int n_items, const void *d_in, vo
                           hipStream_t st);
 
 // K6 (root_music.hip): polynomial roots from the DOUBLE coefficient records -> angles.
+// d_roots (optional, diagnostics): the 2N-2 roots found per item as double2, in the kernel's lane order.
 int launch_root_music(int N, int M, float norm_spacing, int n_items, const void *d_coef, void *d_out,
-                      void *d_status, hipStream_t st);
+                      void *d_status, hipStream_t st, void *d_roots = nullptr);
 
 }  // namespace doa

@@ -30,15 +30,47 @@ template <int N, typename T> __device__ __forceinline__ T null_spectrum(const T 
     return fma((T)2, re, c[0]);
 }
 
+// ---- normalisation to the maximum: 10*log10(out/max(out)), out = 1/Q (reference :140-142) ------------------
+// The reference forms out = 1.0/Q (double division stored to float: correctly rounded) and divides by the
+// maximum in float; an angle is at exactly 0 dB iff its ROUNDED reciprocal equals the largest one (x/x == 1),
+// and find_local_max then takes the first such angle (find_local_max_impl.h:53-56).  The kernels below keep
+// exactly that tie set: v_rcp_f32 / v_log_f32 do the bulk, but every angle that could tie with the maximum goes
+// through IEEE divisions, and 10*log10(r) for r within 1e-5 of 1 is 4.3429448 (r - 1) (r - 1 is exact there;
+// the hardware log2 loses it), so no angle other than a true tie can come out as 0 dB or above.
+constexpr float kDbPerLog2 = 3.0102999566398120f;       // 10 log10(2)
+constexpr float kDbPerUnit = 4.3429448190325183f;       // 10 / ln(10)
+
 __device__ __forceinline__ float db_from_ratio(float out, float mx, float inv_mx)
 {
-    // 10*log10(out/max).  The maximum itself must come out as exactly 0 dB (x/x == 1 in the
-    // reference; inf/inf stays NaN as there), everything else is out*(1/max) through the hardware
-    // log2: 10*log10(r) = (10*log10(2)) * log2(r).
-    // out <= max, so out/max <= 1 in the reference; the reciprocal multiply is clamped to keep that
-    float ratio = (out == mx && mx != INFINITY) ? 1.0f : fminf(out * inv_mx, 1.0f);
-    return 3.0102999566398120f * __log2f(ratio);
+    // general form: out, mx are correctly rounded reciprocals, out <= mx (NaN/inf rows: inf/inf stays NaN as
+    // in the reference)
+    if (out == mx && mx != INFINITY) return kDbPerLog2 * __log2f(1.0f);
+    const float approx = out * inv_mx;
+    float db = kDbPerLog2 * __log2f(fminf(approx, 1.0f));
+    if (approx > 0.99999f) db = kDbPerUnit * (out / mx - 1.0f);      // IEEE division: < 1 since out < mx
+    return db;
 }
+
+// Lean form, from Q itself and its item minimum mn (a normal positive float): max(out) = 1/mn.
+struct LeanNorm {
+    float inv_mn, thr, mx;
+    __device__ __forceinline__ explicit LeanNorm(float mn)
+        : inv_mn(__builtin_amdgcn_rcpf(mn)), thr(mn * 1.000001f), mx(1.0f / mn) {}
+    // dB of one angle; tie = this angle holds the maximum.  Q > thr cannot tie (its reciprocal is > 7 ulp away)
+    // and has Q * (1/mn) >= 1 + 8e-7, i.e. a strictly negative dB through the fast path.
+    __device__ __forceinline__ float db(float q, bool &tie) const
+    {
+        float d = -kDbPerLog2 * __log2f(q * inv_mn);
+        tie = false;
+        if (q <= thr) {                                  // rare: the minimum itself and its near-ties
+            const float o = 1.0f / q;
+            tie = (o == mx);
+            d = tie ? 0.0f : kDbPerUnit * (o / mx - 1.0f);
+        }
+        return d;
+    }
+};
+__device__ __forceinline__ bool lean_norm_ok(float mn) { return (mn >= 1.2e-38f) && (mn < INFINITY); }
 
 // Fast path: P % 4 == 0 and P <= 256*CH.  One wave per item, grid-stride over items so that the
 // z table (4*CH angles per lane) is loaded once per wave and stays in registers.  With PEAK the
@@ -122,7 +154,7 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
                 if constexpr (HAS_Q) {
                     if (live) qout[(size_t)item * P + 4 * lane + 256 * j + e] = q;
                 }
-                out[j][e] = __builtin_amdgcn_rcpf(q);           // 1.0/Q  (:140)
+                out[j][e] = 1.0f / q;                           // 1.0/Q  (:140), correctly rounded as there
                 mx = live ? fmaxf(mx, out[j][e]) : mx;
             }
             // table re-read per chunk: keep the scheduler from hoisting all CH chunks' loads to the top
@@ -143,9 +175,7 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const T *__restrict__ c
                 const int i0 = 4 * lane + 256 * j;
 #pragma unroll
                 for (int e = 3; e >= 0; e--) {
-                    const float o = out[j][e];
-                    const float ratio = (o == mx) ? 1.0f : fminf(o * inv_mx, 1.0f);
-                    const float db = 3.0102999566398120f * __log2f(ratio);       // 10*log10(ratio)
+                    const float db = db_from_ratio(out[j][e], mx, inv_mx);
                     out[j][e] = db;
                     if constexpr (PEAK) {
                         if (FULL || i0 < P) first_zero = (db == 0.0f) ? (i0 + e) : first_zero;
@@ -222,16 +252,152 @@ template <int N, typename T> struct ChebQ {
     }
 };
 
-// The benchmark shape of K4+K5 as its own lean kernel: P == 256*CH exactly (no bounds predicates),
-// num_max_vals == 1 (the peak pick is "first position whose dB equals the maximum": compares land in
-// SGPR pairs, the position search is s_ff1 / s_min on the scalar unit), compiled polynomial size == the
-// array size (unconditional scalar loads of the coefficient record).  Nothing generic is compiled in,
-// which keeps it at ~110 VGPRs (4 waves per SIMD) where the general kernel needs 200+.  Items whose
-// minimum of Q is not a finite positive number (a zero, negative or non-finite null spectrum:
-// non-finite input, in practice) take a slow rolled path that follows the general kernel's semantics
-// literally.
-// MULTI: num_max_vals > 1 (the flowgraph's two sources): same arithmetic, the dB values stay in
-// registers and go through the general peak_pick.
+// The benchmark shape of K4+K5, lean: P == 256*CH exactly (no bounds predicates), compiled polynomial size ==
+// the array size, coefficients wave-uniform.  lean_scan_item is one item of it.  Nothing generic is compiled in, which keeps it at ~110 VGPRs (4 waves per SIMD) where
+// the general kernel needs 200+:
+//   * pass 1 keeps Q itself and its wave minimum (no reciprocal per angle);
+//   * pass 2 is dB = -10 log10(2) log2(Q (1/Qmin)): ONE transcendental per angle; the angles that can tie with the
+//     maximum take LeanNorm::db's exact path;
+//   * num_max_vals == 1: find_local_max's answer is the first angle holding the maximum; the tie compare lands
+//     in an SGPR pair, so the position search (s_ff1, s_min) is scalar work beside the vector pipe;
+//   * num_max_vals > 1 (MULTI, the flowgraph's two sources): the dB values stay in registers and go through the
+//     general peak_pick.
+// Items whose minimum of Q is not a normal positive float (zero, negative or non-finite null spectrum:
+// non-finite input, in practice) take a slow rolled path that follows the general kernel's semantics literally.
+template <int N, int CH, typename T, bool MULTI>
+__device__ __forceinline__ void lean_scan_item_irregular(const T (&c)[2 * N], float (&qf)[CH][4], const T *__restrict__ ztab,
+                                                      float *__restrict__ row, const float *__restrict__ xs,
+                                                      float *__restrict__ pk_val_item, float *__restrict__ pk_loc_item,
+                                                      int M, int lane);
+
+template <int N, int CH, typename T, bool MULTI>
+__device__ __forceinline__ void lean_scan_item(const T (&c)[2 * N], const T (&zr)[CH][4], const T (&zi)[CH][4],
+                                               const T *__restrict__ ztab, float *__restrict__ row,
+                                               const float *__restrict__ xs, float *__restrict__ pk_val_item,
+                                               float *__restrict__ pk_loc_item, int M, int lane)
+{
+    constexpr int P = 256 * CH;
+    // pass 1: the null spectrum itself (no reciprocal) and its minimum over the item
+    float qf[CH][4];
+    float mn = INFINITY;
+    if constexpr (N <= 4 && sizeof(T) == 8) {
+        const ChebQ<N, T> Q(c);
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                qf[j][e] = (float)Q(zr[j][e], zi[j][e]);
+                mn = fminf(mn, qf[j][e]);
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                qf[j][e] = (float)null_spectrum<N, T>(c, zr[j][e], zi[j][e]);
+                mn = fminf(mn, qf[j][e]);
+            }
+    }
+    mn = wave_allreduce_min(mn);
+    if (lean_norm_ok(mn)) {
+        const LeanNorm nrm(mn);
+        if constexpr (MULTI) {
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    bool tie;
+                    qf[j][e] = nrm.db(qf[j][e], tie);
+                }
+                store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
+                               make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
+            }
+            peak_pick<CH>(qf, lane, P, M, xs, pk_val_item, pk_loc_item);
+        } else {
+            int pos = INT_MAX;
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                float db[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    bool tie;
+                    db[e] = nrm.db(qf[j][e], tie);
+                    const unsigned long long at_max = __builtin_amdgcn_ballot_w64(tie);
+                    const int cand = at_max ? (4 * (int)__builtin_ctzll(at_max) + 256 * j + e) : INT_MAX;
+                    pos = min(pos, cand);
+                }
+                store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(db[0], db[1], db[2], db[3]));
+            }
+            // (the minimum itself always ties, so pos is a valid angle; the clamp only keeps a broken invariant from
+            // turning into a wild address)
+            if (lane == 0) { pk_val_item[0] = 0.0f; pk_loc_item[0] = xs[min(pos, P - 1)]; }
+        }
+    } else {
+        lean_scan_item_irregular<N, CH, T, MULTI>(c, qf, ztab, row, xs, pk_val_item, pk_loc_item, M, lane);
+    }
+}
+
+// rare: follow the general semantics (db_from_ratio, arma index_max) without unrolling
+template <int N, int CH, typename T, bool MULTI>
+__device__ __forceinline__ void lean_scan_item_irregular(const T (&c)[2 * N], float (&qf)[CH][4], const T *__restrict__ ztab,
+                                                      float *__restrict__ row, const float *__restrict__ xs,
+                                                      float *__restrict__ pk_val_item, float *__restrict__ pk_loc_item,
+                                                      int M, int lane)
+{
+    constexpr int P = 256 * CH;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < CH; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) mx = fmaxf(mx, 1.0f / qf[j][e]);
+    mx = wave_allreduce_max(mx);
+    const float inv_mx = __builtin_amdgcn_rcpf(mx);
+    if constexpr (MULTI) {
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) qf[j][e] = db_from_ratio(1.0f / qf[j][e], mx, inv_mx);
+            store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
+                           make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
+        }
+        peak_pick<CH>(qf, lane, P, M, xs, pk_val_item, pk_loc_item);
+        return;
+    }
+    float bv = 0.f;
+    int bi = INT_MAX;
+    float v0 = 0.f;
+#pragma unroll 1
+    for (int j = 0; j < CH; j++)
+#pragma unroll 1
+        for (int e = 0; e < 4; e++) {
+            const int i = 4 * lane + 256 * j + e;
+            const float o = 1.0f / (float)null_spectrum<N, T>(c, (T)ztab[2 * i], (T)ztab[2 * i + 1]);
+            const float db = db_from_ratio(o, mx, inv_mx);
+            row[i] = db;
+            if (i == 0) v0 = db;
+            if (db > -INFINITY && cand_better(db, i, bv, bi)) { bv = db; bi = i; }
+        }
+    wave_argbest(bv, bi);
+    v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), 0));
+    if (lane == 0) {
+        pk_val_item[0] = (bi == INT_MAX) ? v0 : bv;
+        pk_loc_item[0] = xs[(bi == INT_MAX) ? 0 : bi];
+    }
+}
+
+// this lane's 4*CH table entries z_i = (cos psi_i, sin psi_i), i = 4*lane + 256*j + e, into registers
+template <int CH, typename T>
+__device__ __forceinline__ void lean_load_table(const T *__restrict__ ztab, int lane, T (&zr)[CH][4], T (&zi)[CH][4])
+{
+#pragma unroll
+    for (int j = 0; j < CH; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = 4 * lane + 256 * j + e;
+            zr[j][e] = ztab[2 * i]; zi[j][e] = ztab[2 * i + 1];
+        }
+}
+
 template <int N, int CH, typename T, bool MULTI = false>
 __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                                float *__restrict__ spec, int n_items,
@@ -246,13 +412,9 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
     const int n_waves = gridDim.x * (blockDim.x / kWave);
     T zr[CH][4], zi[CH][4];
-#pragma unroll
-    for (int j = 0; j < CH; j++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int i = 4 * lane + 256 * j + e;
-            zr[j][e] = ztab[2 * i]; zi[j][e] = ztab[2 * i + 1];
-        }
+    lean_load_table<CH, T>(ztab, lane, zr, zi);
+    // coefficient records arrive through scalar loads; the next item's record is requested before this item's
+    // arithmetic so that its latency hides behind it
     T c[2 * N], c_next[2 * N];
     if (wave < n_items) {
 #pragma unroll
@@ -266,104 +428,8 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
 #pragma unroll
             for (int k = 0; k < 2 * N; k++) c_next[k] = coef[(size_t)nxt * (2 * N) + k];
         }
-        // pass 1: the null spectrum itself (no reciprocal) and its minimum over the item
-        float qf[CH][4];
-        float mn = INFINITY;
-        if constexpr (N <= 4 && sizeof(T) == 8) {
-            const ChebQ<N, T> Q(c);
-#pragma unroll
-            for (int j = 0; j < CH; j++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    qf[j][e] = (float)Q(zr[j][e], zi[j][e]);
-                    mn = fminf(mn, qf[j][e]);
-                }
-        } else {
-#pragma unroll
-            for (int j = 0; j < CH; j++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    qf[j][e] = (float)null_spectrum<N, T>(c, zr[j][e], zi[j][e]);
-                    mn = fminf(mn, qf[j][e]);
-                }
-        }
-        mn = wave_allreduce_min(mn);
-        float *row = spec + (size_t)item * P;
-        if ((mn > 0.0f) && (mn < INFINITY)) {
-            // pass 2: 10 log10((1/Q)/max(1/Q)) = -10 log10(2) * log2(Q/Qmin): one transcendental per angle.
-            // 1/Qmin is biased down by 2 ulp so that Qmin/Qmin <= 1 whatever v_rcp rounds to; t <= 1 is
-            // then "this angle holds the maximum" (0 dB exactly, as x/x == 1 in the reference), and the
-            // first such angle of the item is find_local_max's answer for num_max_vals == 1.  The compare
-            // lands in an SGPR pair, so the position search is scalar work beside the vector pipe.
-            const float inv_mn = __builtin_amdgcn_rcpf(mn) * 0.99999976158142f;
-            if constexpr (MULTI) {
-#pragma unroll
-                for (int j = 0; j < CH; j++) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        qf[j][e] = fmaf(-3.0102999566398120f, __log2f(fmaxf(qf[j][e] * inv_mn, 1.0f)), 0.0f);
-                    store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
-                                   make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
-                }
-                peak_pick<CH>(qf, lane, P, M, xs, pk_val + (size_t)item * M, pk_loc + (size_t)item * M);
-            } else {
-                int pos = INT_MAX;
-#pragma unroll
-                for (int j = 0; j < CH; j++) {
-                    float db[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float t = qf[j][e] * inv_mn;
-                        const unsigned long long at_max = __builtin_amdgcn_ballot_w64(t <= 1.0f);
-                        const int cand = at_max ? (4 * (int)__builtin_ctzll(at_max) + 256 * j + e) : INT_MAX;
-                        pos = min(pos, cand);
-                        db[e] = fmaf(-3.0102999566398120f, __log2f(fmaxf(t, 1.0f)), 0.0f);     // +0.0 at the maximum
-                    }
-                    store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(db[0], db[1], db[2], db[3]));
-                }
-                if (lane == 0) { pk_val[item] = 0.0f; pk_loc[item] = xs[pos]; }
-            }
-        } else {
-            // rare: follow the general semantics (db_from_ratio, arma index_max) without unrolling
-            float mx = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < CH; j++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_amdgcn_rcpf(qf[j][e]));
-            mx = wave_allreduce_max(mx);
-            const float inv_mx = __builtin_amdgcn_rcpf(mx);
-            if constexpr (MULTI) {
-#pragma unroll
-                for (int j = 0; j < CH; j++) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) qf[j][e] = db_from_ratio(__builtin_amdgcn_rcpf(qf[j][e]), mx, inv_mx);
-                    store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
-                                   make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
-                }
-                peak_pick<CH>(qf, lane, P, M, xs, pk_val + (size_t)item * M, pk_loc + (size_t)item * M);
-                continue;
-            }
-            float bv = 0.f;
-            int bi = INT_MAX;
-            float v0 = 0.f;
-#pragma unroll 1
-            for (int j = 0; j < CH; j++)
-#pragma unroll 1
-                for (int e = 0; e < 4; e++) {
-                    const int i = 4 * lane + 256 * j + e;
-                    const float o = __builtin_amdgcn_rcpf((float)null_spectrum<N, T>(c, (T)ztab[2 * i], (T)ztab[2 * i + 1]));
-                    const float db = db_from_ratio(o, mx, inv_mx);
-                    row[i] = db;
-                    if (i == 0) v0 = db;
-                    if (db > -INFINITY && cand_better(db, i, bv, bi)) { bv = db; bi = i; }
-                }
-            wave_argbest(bv, bi);
-            v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), 0));
-            if (lane == 0) {
-                pk_val[item] = (bi == INT_MAX) ? v0 : bv;
-                pk_loc[item] = xs[(bi == INT_MAX) ? 0 : bi];
-            }
-        }
+        lean_scan_item<N, CH, T, MULTI>(c, zr, zi, ztab, spec + (size_t)item * P, xs, pk_val + (size_t)item * M,
+                                        pk_loc + (size_t)item * M, M, lane);
     }
 }
 
@@ -416,14 +482,17 @@ __global__ __launch_bounds__(256) void music_scan_stream_kernel(const T *__restr
             q[0] = t.x; q[1] = t.y; q[2] = t.z; q[3] = t.w;
             return true;
         };
-        if ((mn > 0.0f) && (mn < INFINITY)) {
-            const float inv_mn = __builtin_amdgcn_rcpf(mn) * 0.99999976158142f;
+        if (lean_norm_ok(mn)) {
+            const LeanNorm nrm(mn);
 #pragma unroll 1
             for (int j = 0; j < n_chunks; j++) {
                 float q[4];
                 if (reload(j, q)) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) q[e] = fmaf(-3.0102999566398120f, __log2f(fmaxf(q[e] * inv_mn, 1.0f)), 0.0f);
+                    for (int e = 0; e < 4; e++) {
+                        bool tie;
+                        q[e] = nrm.db(q[e], tie);
+                    }
                     store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(q[0], q[1], q[2], q[3]));
                 }
             }
@@ -434,7 +503,7 @@ __global__ __launch_bounds__(256) void music_scan_stream_kernel(const T *__restr
                 float q[4];
                 if (reload(j, q)) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_amdgcn_rcpf(q[e]));
+                    for (int e = 0; e < 4; e++) mx = fmaxf(mx, 1.0f / q[e]);
                 }
             }
             mx = wave_allreduce_max(mx);
@@ -444,7 +513,7 @@ __global__ __launch_bounds__(256) void music_scan_stream_kernel(const T *__restr
                 float q[4];
                 if (reload(j, q)) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) q[e] = db_from_ratio(__builtin_amdgcn_rcpf(q[e]), mx, inv_mx);
+                    for (int e = 0; e < 4; e++) q[e] = db_from_ratio(1.0f / q[e], mx, inv_mx);
                     store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(q[0], q[1], q[2], q[3]));
                 }
             }
@@ -471,12 +540,12 @@ __global__ __launch_bounds__(256) void music_scan_generic_kernel(const T *__rest
         for (int i = lane; i < P; i += kWave) {
             const float q = (float)null_spectrum<N, T>(c, ztab[2 * i], ztab[2 * i + 1]);
             if (qout) qout[(size_t)item * P + i] = q;
-            mx = fmaxf(mx, __builtin_amdgcn_rcpf(q));
+            mx = fmaxf(mx, 1.0f / q);
         }
         mx = wave_allreduce_max(mx);
         const float inv_mx = __builtin_amdgcn_rcpf(mx);
         for (int i = lane; i < P; i += kWave) {
-            const float o = __builtin_amdgcn_rcpf((float)null_spectrum<N, T>(c, ztab[2 * i], ztab[2 * i + 1]));
+            const float o = 1.0f / (float)null_spectrum<N, T>(c, ztab[2 * i], ztab[2 * i + 1]);
             spec[(size_t)item * P + i] = db_from_ratio(o, mx, inv_mx);
         }
     }

@@ -22,6 +22,7 @@ struct doa_music_pipeline {
     int max_batch = 0;
     int bits = 64;
     int device = 0;
+    unsigned stages = 7;           // bit 0 K1, bit 1 K2+K3, bit 2 K4+K5 (doa_music_pipeline_set_stages)
     doa::MusicTables music;
     doa::PeakTables peaks;
     doa::DevBuf d_cov, d_coef, d_spec, d_scratch, d_gain;
@@ -37,13 +38,7 @@ struct doa_music_pipeline {
 static int run_dev(doa_music_pipeline *h, int n, const void *const *d_in, void *cov, void *spec, void *mx, void *am,
                    size_t item_off, hipStream_t st, int lane = 0)
 {
-    // DOA_PIPE_SKIP=cov,evd,scan: profiling aid that drops stages (outputs are then meaningless)
-    unsigned skip = 0;      // read per call so that a profiling script can populate the intermediates first
-    if (const char *e = getenv("DOA_PIPE_SKIP")) {
-        if (strstr(e, "cov")) skip |= 1;
-        if (strstr(e, "evd")) skip |= 2;
-        if (strstr(e, "scan")) skip |= 4;
-    }
+    const unsigned skip = ~h->stages & 7u;      // doa_music_pipeline_set_stages (profiling aid; 0 in production)
     int rc = DOA_OK;
     if (!(skip & 1)) rc = doa::launch_autocorrelate(h->N, h->K, h->ovl, h->avg, n, d_in, cov, st,
                                                      h->has_gain ? h->d_gain.p : nullptr, h->d_work[lane].p);
@@ -139,6 +134,14 @@ int doa_music_pipeline_fuse_antenna_correction(doa_music_pipeline_t *h, const fl
     if (rc != DOA_OK) return rc;
     DOA_HIP_TRY(hipMemcpy(h->d_gain.p, w, sizeof(float2) * N * N, hipMemcpyHostToDevice));
     h->has_gain = true;
+    return DOA_OK;
+}
+
+int doa_music_pipeline_set_stages(doa_music_pipeline_t *h, int stage_mask)
+{
+    doa::clear_error();
+    if (!h || stage_mask < 0 || stage_mask > 7) { doa::set_error("music_pipeline_set_stages: bad arguments"); return DOA_ERR_INVALID_ARG; }
+    h->stages = (unsigned)stage_mask;
     return DOA_OK;
 }
 

@@ -7,8 +7,8 @@
 //   (:80-86) — keep the roots strictly inside the unit circle (:122-127), take the num_targets
 //   closest to it (:131-141), angle = acos(arg(z) / (2 pi d)) in degrees, sorted ascending (:144).
 //
-// Here the roots come from a batched Aberth-Ehrlich iteration in double, one lane per item (the
-// polynomial has degree 2N-2 <= 30, a few hundred flops per sweep).  Root-MUSIC's root pairs
+// Here the roots come from a batched Aberth-Ehrlich iteration in double, one root per lane (the
+// polynomial has degree 2N-2 <= 30; root_music_group_kernel).  Root-MUSIC's root pairs
 // (z, 1/conj(z)) sit within ~1e-4 of each other at the unit circle, which is why a float solver
 // (the reference's cgeev) is itself only ~0.01 degree accurate; see DESIGN.md "parity".
 // Edge cases follow the reference: with fewer than num_targets interior roots the missing slots
@@ -23,135 +23,6 @@ namespace doa {
 
 // |p(z)| <= kResidualFloor * (degree+1) * sum |c_m||z|^m counts as "zero to working precision" (16 eps)
 constexpr double kResidualFloor = 16.0 * 2.220446049250313e-16;
-
-template <int N, bool UNROLL>
-__device__ __forceinline__ void aberth_roots(const double (&cr)[2 * N - 1], const double (&ci)[2 * N - 1],
-                                             double (&zr)[2 * N - 2], double (&zi)[2 * N - 2])
-{
-    constexpr int D = 2 * N - 2;
-    constexpr int U = UNROLL ? D : 1;
-    // start: points of unequal radius around the unit circle (an exactly circular start is a fixed
-    // configuration for this conjugate-reciprocal polynomial)
-#pragma unroll U
-    for (int k = 0; k < D; k++) {
-        const double ang = 2.0 * M_PI * (k + 0.37) / D;
-        const double rad = 0.75 + 0.5 * ((k * 0.6180339887498949) - floor(k * 0.6180339887498949));
-        double s, c;
-        sincos(ang, &s, &c);
-        zr[k] = rad * c; zi[k] = rad * s;
-    }
-    for (int it = 0; it < 100; it++) {
-        double worst = 0.0;
-#pragma unroll U
-        for (int k = 0; k < D; k++) {
-            // Horner for p and p' at z_k
-            double pr = cr[D], pi = ci[D], dr = 0.0, di = 0.0;
-            // running bound of the rounding error of p(z_k): sum |c_m| |z_k|^m (|c_m| taken as |re|+|im|)
-            const double rk = (double)sqrtf((float)(zr[k] * zr[k] + zi[k] * zi[k]));
-            double eb = fabs(cr[D]) + fabs(ci[D]);
-#pragma unroll U
-            for (int m = D - 1; m >= 0; m--) {
-                const double ndr = dr * zr[k] - di * zi[k] + pr;
-                const double ndi = dr * zi[k] + di * zr[k] + pi;
-                dr = ndr; di = ndi;
-                const double npr = pr * zr[k] - pi * zi[k] + cr[m];
-                const double npi = pr * zi[k] + pi * zr[k] + ci[m];
-                pr = npr; pi = npi;
-                eb = fma(eb, rk, fabs(cr[m]) + fabs(ci[m]));
-            }
-            // |p(z_k)| at its rounding floor: the root is as good as double Horner can tell (Root-MUSIC's
-            // pairs z, 1/conj(z) sit 1e-3..1e-5 apart, so the step itself never falls to 1e-15 relative:
-            // without this test such items ran to the iteration cap)
-            const double floor_k = kResidualFloor * (D + 1) * eb;
-            if (pr * pr + pi * pi <= floor_k * floor_k) continue;
-            // w = p/p'
-            const double dn = dr * dr + di * di;
-            double wr, wi;
-            if (dn > 0.0) { wr = (pr * dr + pi * di) / dn; wi = (pi * dr - pr * di) / dn; }
-            else { wr = 1e-3; wi = 1e-3; }
-            // s = sum_{j != k} 1/(z_k - z_j)
-            double sr = 0.0, si = 0.0;
-#pragma unroll U
-            for (int j = 0; j < D; j++) {
-                if (j == k) continue;
-                const double er = zr[k] - zr[j], ei = zi[k] - zi[j];
-                const double en = er * er + ei * ei;
-                if (en > 0.0) { sr += er / en; si -= ei / en; }
-            }
-            // delta = w / (1 - w s)
-            const double qr = 1.0 - (wr * sr - wi * si), qi = -(wr * si + wi * sr);
-            const double qn = qr * qr + qi * qi;
-            double er = wr, ei = wi;
-            if (qn > 0.0) { er = (wr * qr + wi * qi) / qn; ei = (wi * qr - wr * qi) / qn; }
-            zr[k] -= er; zi[k] -= ei;
-            const double rel = (er * er + ei * ei) / (1.0 + zr[k] * zr[k] + zi[k] * zi[k]);
-            worst = fmax(worst, rel);
-        }
-        if (worst < 1e-29) break;   // squared relative step: steps below ~3e-15 are rounding noise
-    }
-}
-
-template <int N>
-__global__ __launch_bounds__(64) void root_music_kernel(const double *__restrict__ coef, float *__restrict__ out,
-                                                        int *__restrict__ status, int n_items, int M, double two_pi_d)
-{
-    constexpr bool UNROLL = (N <= 4);
-    constexpr int D = 2 * N - 2;
-    constexpr int U = UNROLL ? D : 1;
-    const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= n_items) return;
-    const double *co = coef + (size_t)item * (2 * N);
-    // polynomial c[k], k = 0..2N-2: c[N-1-l] = u_l, c[N-1+l] = conj(u_l)   (:71-78)
-    double cr[2 * N - 1], ci[2 * N - 1];
-    cr[N - 1] = co[0]; ci[N - 1] = 0.0;
-#pragma unroll U
-    for (int l = 1; l < N; l++) {
-        const double ur = co[2 * l - 1], ui = co[2 * l];
-        cr[N - 1 - l] = ur; ci[N - 1 - l] = ui;
-        cr[N - 1 + l] = ur; ci[N - 1 + l] = -ui;
-    }
-    double zr[D], zi[D];
-    aberth_roots<N, UNROLL>(cr, ci, zr, zi);
-
-    // dist = 1 - |z|, keep dist > 0, pick the M smallest, one at a time (:122-141)
-    double dist[D];
-    int n_inside = 0;
-#pragma unroll U
-    for (int k = 0; k < D; k++) {
-        dist[k] = 1.0 - sqrt(zr[k] * zr[k] + zi[k] * zi[k]);
-        if (!(dist[k] > 0.0)) dist[k] = -1.0;   // outside: excluded
-        else n_inside++;
-    }
-    float *o = out + (size_t)item * M;
-    if (n_inside == 0) {
-        if (status) status[item] = 1;
-        for (int j = 0; j < M; j++) o[j] = __builtin_nanf("");
-        return;
-    }
-    if (status) status[item] = 0;
-    float aoa[DOA_MAX_PEAKS];
-    for (int j = 0; j < M; j++) {
-        int best = -1;
-#pragma unroll U
-        for (int k = 0; k < D; k++)
-            if (dist[k] > 0.0 && (best < 0 || dist[k] < dist[best])) best = k;
-        double ang = 0.0;                         // exhausted: arg(inf + 0i) = 0 -> 90 degrees
-        if (best >= 0) {
-            double br = 0.0, bi = 0.0;
-#pragma unroll U
-            for (int k = 0; k < D; k++) if (k == best) { br = zr[k]; bi = zi[k]; dist[k] = -1.0; }
-            ang = atan2(bi, br);
-        }
-        aoa[j] = (float)(180.0 * acos(ang / two_pi_d) / M_PI);
-    }
-    for (int a = 1; a < M; a++) {                 // ascending (:144); NaNs keep their slots
-        const float t = aoa[a];
-        int b = a - 1;
-        while (b >= 0 && aoa[b] > t) { aoa[b + 1] = aoa[b]; b--; }
-        aoa[b + 1] = t;
-    }
-    for (int j = 0; j < M; j++) o[j] = aoa[j];
-}
 
 // ---------------------------------------------------------------------------------------------
 // Group-parallel Aberth-Ehrlich: GR lanes (the power of two >= 2N-2) share one item, one root per
@@ -184,7 +55,7 @@ __device__ __forceinline__ double fast_rcp(double x)
 template <int GR, int DEG = GR>
 __global__ __launch_bounds__(64) void root_music_group_kernel(const double *__restrict__ coef, float *__restrict__ out,
                                                               int *__restrict__ status, int n_items, int N, int M,
-                                                              double two_pi_d)
+                                                              double two_pi_d, double2 *__restrict__ roots_out)
 {
     constexpr int IPW = kWave / GR;
     const int lane = threadIdx.x & (kWave - 1);
@@ -230,7 +101,7 @@ __global__ __launch_bounds__(64) void root_music_group_kernel(const double *__re
             eb = fma(eb, rk, ca[m]);             // rounding-error bound of p(z): sum |c_m| |z|^m
         }
         const double floor_k = kResidualFloor * (D + 1) * eb;
-        const bool at_floor = (pr * pr + pi * pi <= floor_k * floor_k);   // see aberth_roots
+        const bool at_floor = (pr * pr + pi * pi <= floor_k * floor_k);
         // (coefficients above degree D are zero, so starting the recurrence at DEG >= D changes nothing)
         const double dn = dr * dr + di * di;
         double wr = 1e-3, wi = 1e-3;
@@ -254,6 +125,15 @@ __global__ __launch_bounds__(64) void root_music_group_kernel(const double *__re
         }
         if (__ballot(rel >= 1e-29) == 0ull) break;   // every root of every group of the wave has converged
     }
+    {
+        // a non-finite polynomial (non-finite covariance item) has no roots: without this the iteration above stops at
+        // once -- every comparison with NaN is false -- and the starting points would pass for roots
+        double csum = 0.0;
+#pragma unroll
+        for (int m = 0; m <= GR; m++) csum += ca[m];
+        if (!(csum < INFINITY)) { zr = __builtin_nan(""); zi = __builtin_nan(""); }
+    }
+    if (roots_out && real_item && is_root) roots_out[(size_t)item * D + k] = make_double2(zr, zi);    // diagnostics
     // dist = 1 - |z|; keep dist > 0; the M smallest, one at a time (:122-141)
     double dist = is_root ? 1.0 - sqrt(zr * zr + zi * zi) : -1.0;
     if (!(dist > 0.0)) dist = -1.0;
@@ -300,48 +180,30 @@ __global__ __launch_bounds__(64) void root_music_group_kernel(const double *__re
 
 template <int GR, int DEG = GR>
 static void launch_root_group(int N, int M, int n_items, const void *d_coef, void *d_out, void *d_status, double two_pi_d,
-                              hipStream_t st)
+                              hipStream_t st, void *d_roots)
 {
     constexpr int IPW = kWave / GR;
     dim3 block(64), grid((n_items + IPW - 1) / IPW);
     hipLaunchKernelGGL((root_music_group_kernel<GR, DEG>), grid, block, 0, st, (const double *)d_coef, (float *)d_out,
-                       (int *)d_status, n_items, N, M, two_pi_d);
+                       (int *)d_status, n_items, N, M, two_pi_d, (double2 *)d_roots);
 }
 
 int launch_root_music(int N, int M, float norm_spacing, int n_items, const void *d_coef, void *d_out, void *d_status,
-                      hipStream_t st)
+                      hipStream_t st, void *d_roots)
 {
     if (n_items <= 0) return DOA_OK;
     const double two_pi_d = 2 * M_PI * (double)norm_spacing;   // 2*datum::pi*d_norm_spacing, float promoted (:135)
-    static const int serial = [] { const char *e = getenv("DOA_ROOT_SERIAL"); return e ? atoi(e) : 0; }();
     if (N < 2 || N > DOA_MAX_ANT_ELE) {
         set_error("rootMUSIC: num_ant_ele=%d outside the built range 2..%d", N, DOA_MAX_ANT_ELE);
         return DOA_ERR_UNSUPPORTED;
     }
-    if (!serial) {
-        const int D = 2 * N - 2;
-        if (D <= 2) launch_root_group<2>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
-        else if (D <= 4) launch_root_group<4>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
-        else if (D == 6) launch_root_group<8, 6>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
-        else if (D <= 8) launch_root_group<8>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
-        else if (D <= 16) launch_root_group<16>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
-        else launch_root_group<32>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st);
-        DOA_HIP_TRY(hipGetLastError());
-        return DOA_OK;
-    }
-    dim3 block(64), grid((n_items + 63) / 64);
-    switch (N) {
-#define DOA_ROOT_CASE(n)                                                                                   \
-    case n:                                                                                                \
-        hipLaunchKernelGGL(root_music_kernel<n>, grid, block, 0, st, (const double *)d_coef, (float *)d_out, \
-                           (int *)d_status, n_items, M, two_pi_d);                                         \
-        break;
-        DOA_ROOT_CASE(2) DOA_ROOT_CASE(3) DOA_ROOT_CASE(4)
-#undef DOA_ROOT_CASE
-    default:
-        set_error("rootMUSIC: the one-lane-per-item kernel is only built for num_ant_ele <= 4");
-        return DOA_ERR_UNSUPPORTED;
-    }
+    const int D = 2 * N - 2;
+    if (D <= 2) launch_root_group<2>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st, d_roots);
+    else if (D <= 4) launch_root_group<4>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st, d_roots);
+    else if (D == 6) launch_root_group<8, 6>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st, d_roots);
+    else if (D <= 8) launch_root_group<8>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st, d_roots);
+    else if (D <= 16) launch_root_group<16>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st, d_roots);
+    else launch_root_group<32>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st, d_roots);
     DOA_HIP_TRY(hipGetLastError());
     return DOA_OK;
 }
@@ -357,7 +219,7 @@ struct doa_rootMUSIC_linear_array {
     int bits = 64;
     int device = 0;
     hipStream_t stream = nullptr;
-    doa::DevBuf d_in, d_out, d_coef, d_status;
+    doa::DevBuf d_in, d_out, d_coef, d_status, d_roots;
     doa::PinnedBuf h_status;
 };
 
@@ -397,7 +259,8 @@ doa_rootMUSIC_linear_array_t *doa_rootMUSIC_linear_array_create(float norm_spaci
 void doa_rootMUSIC_linear_array_destroy(doa_rootMUSIC_linear_array_t *h)
 {
     if (!h) return;
-    h->d_in.release(); h->d_out.release(); h->d_coef.release(); h->d_status.release(); h->h_status.release();
+    h->d_in.release(); h->d_out.release(); h->d_coef.release(); h->d_status.release(); h->d_roots.release();
+    h->h_status.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -453,6 +316,40 @@ int doa_rootMUSIC_linear_array_work(doa_rootMUSIC_linear_array_t *h, int noutput
                            "(the reference raises in arma::index_min here)", i);
             return DOA_ERR_NUMERIC;
         }
+    return noutput_items;
+}
+
+int doa_rootMUSIC_linear_array_debug(doa_rootMUSIC_linear_array_t *h, int noutput_items, const void *input_items0,
+                                     void *output_items0, void *roots_out, int *status_out)
+{
+    doa::clear_error();
+    if (!h || noutput_items <= 0 || !input_items0 || !output_items0) {
+        doa::set_error("rootMUSIC_linear_array_debug: bad arguments");
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
+    const int D = 2 * h->N - 2;
+    const size_t in_bytes = (size_t)noutput_items * h->N * h->N * sizeof(float2);
+    const size_t out_bytes = (size_t)noutput_items * h->M * sizeof(float);
+    const size_t root_bytes = (size_t)noutput_items * D * sizeof(double2);
+    int rc = h->d_in.reserve(in_bytes);
+    if (rc == DOA_OK) rc = h->d_out.reserve(out_bytes);
+    if (rc == DOA_OK) rc = h->d_roots.reserve(root_bytes);
+    if (rc == DOA_OK) rc = h->d_coef.reserve((size_t)noutput_items * doa::coef_stride(h->N) * sizeof(double));
+    if (rc == DOA_OK) rc = h->d_status.reserve((size_t)noutput_items * sizeof(int));
+    if (rc != DOA_OK) return rc;
+    DOA_HIP_TRY(hipMemcpyAsync(h->d_in.p, input_items0, in_bytes, hipMemcpyHostToDevice, h->stream));
+    rc = doa::launch_music_evd(h->N, h->M, noutput_items, h->d_in.p, nullptr, h->d_coef.p, nullptr, h->bits, h->stream);
+    if (rc == DOA_OK)
+        rc = doa::launch_root_music(h->N, h->M, h->norm_spacing, noutput_items, h->d_coef.p, h->d_out.p, h->d_status.p,
+                                    h->stream, h->d_roots.p);
+    if (rc != DOA_OK) return rc;
+    DOA_HIP_TRY(hipMemcpyAsync(output_items0, h->d_out.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (roots_out) DOA_HIP_TRY(hipMemcpyAsync(roots_out, h->d_roots.p, root_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (status_out)
+        DOA_HIP_TRY(hipMemcpyAsync(status_out, h->d_status.p, (size_t)noutput_items * sizeof(int), hipMemcpyDeviceToHost,
+                                   h->stream));
+    DOA_HIP_TRY(hipStreamSynchronize(h->stream));
     return noutput_items;
 }
 

@@ -82,6 +82,7 @@ SIGNATURES = {
     "doa_rootMUSIC_linear_array_create": (_vp, [C.c_float, C.c_int, C.c_int]),
     "doa_rootMUSIC_linear_array_destroy": (None, [_vp]),
     "doa_rootMUSIC_linear_array_work": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "doa_rootMUSIC_linear_array_debug": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "doa_rootMUSIC_linear_array_work_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "doa_antenna_correction_create": (_vp, [C.c_int, C.c_char_p]),
     "doa_antenna_correction_destroy": (None, [_vp]),
@@ -96,6 +97,7 @@ SIGNATURES = {
     "doa_calibrate_lin_array_work_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "doa_music_pipeline_create": (_vp, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]),
     "doa_music_pipeline_destroy": (None, [_vp]),
+    "doa_music_pipeline_set_stages": (C.c_int, [_vp, C.c_int]),
     "doa_music_pipeline_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp, _vp]),
     "doa_music_pipeline_work": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp]),
     "doa_compass_mean_create": (_vp, [C.c_int]),

@@ -257,6 +257,17 @@ class rootMUSIC_linear_array(_Block):
                                                              C.c_void_p(int(d_out_ptr)), _stream_ptr(stream)))
 
 
+    def debug(self, R_items: np.ndarray):
+        """(angles [n, M] float32, roots [n, 2N-2] complex128, status [n] int32) for parity tests."""
+        a = np.ascontiguousarray(R_items, dtype=_C64).reshape(-1, self.num_ant_ele ** 2)
+        n = a.shape[0]
+        ang = np.empty((n, self.num_targets), dtype=_F32)
+        roots = np.empty((n, 2 * self.num_ant_ele - 2), dtype=np.complex128)
+        status = np.empty(n, dtype=np.int32)
+        check(lib.doa_rootMUSIC_linear_array_debug(self._h, n, _vp(a), _vp(ang), _vp(roots), _vp(status)))
+        return ang, roots, status
+
+
 class calibrate_lin_array(_Block):
     """doa.calibrate_lin_array(norm_spacing, num_ant_ele, pilot_angle) — gr::sync_block, vlen N^2
     complex in, vlen N complex out (reference lib/calibrate_lin_array_impl.cc:46-75)."""
@@ -303,6 +314,10 @@ class music_pipeline(_Block):
 
     def fuse_antenna_correction(self, correction) -> None:
         _fuse(lib.doa_music_pipeline_fuse_antenna_correction, self._h, correction, self.inputs)
+
+    def set_stages(self, cov=True, evd=True, scan=True) -> None:
+        """Profiling aid: drop stages from later work_dev calls (their outputs keep the previous call's values)."""
+        check(lib.doa_music_pipeline_set_stages(self._h, (1 if cov else 0) | (2 if evd else 0) | (4 if scan else 0)))
 
     def work_dev(self, noutput_items, d_input_ptrs, d_cov_ptr, d_spec_ptr, d_max_ptr, d_argmax_ptr, stream=None) -> int:
         return check(lib.doa_music_pipeline_work_dev(

@@ -165,6 +165,13 @@ DOA_HIP_API doa_rootMUSIC_linear_array_t *doa_rootMUSIC_linear_array_create(floa
 DOA_HIP_API void doa_rootMUSIC_linear_array_destroy(doa_rootMUSIC_linear_array_t *h);
 DOA_HIP_API int doa_rootMUSIC_linear_array_work(doa_rootMUSIC_linear_array_t *h, int noutput_items,
                                                 const void *input_items0, void *output_items0);
+/* Diagnostics for parity tests (as doa_MUSIC_lin_array_debug): besides the angles, the 2*num_ant_ele-2 polynomial
+ * roots the solver found per item (roots_out: interleaved re, im doubles; may be NULL) and the per-item status
+ * (status_out: 1 = no root strictly inside the unit circle, the case in which the reference raises inside
+ * arma::index_min and doa_..._work returns DOA_ERR_NUMERIC; may be NULL).  Always returns noutput_items on success. */
+DOA_HIP_API int doa_rootMUSIC_linear_array_debug(doa_rootMUSIC_linear_array_t *h, int noutput_items,
+                                                 const void *input_items0, void *output_items0,
+                                                 void *roots_out, int *status_out);
 DOA_HIP_API int doa_rootMUSIC_linear_array_work_dev(doa_rootMUSIC_linear_array_t *h,
                                                     int noutput_items, const void *d_input_items0,
                                                     void *d_output_items0, void *hip_stream);
@@ -234,6 +241,10 @@ DOA_HIP_API int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput
                                             const void *const *d_input_items, void *d_cov_out,
                                             void *d_spectrum_out, void *d_max_out,
                                             void *d_argmax_out, void *hip_stream);
+/* Profiling aid: which stages later work_dev calls on this handle launch (bit 0 = K1 covariance, bit 1 = K2+K3
+ * EVD, bit 2 = K4+K5 scan + peak pick; default 7).  A dropped stage leaves its outputs as the previous call
+ * wrote them, so a profiler can time one kernel on valid intermediates; not for production use. */
+DOA_HIP_API int doa_music_pipeline_set_stages(doa_music_pipeline_t *h, int stage_mask);
 /* The same three blocks on HOST buffers (the layouts the GNU Radio scheduler hands to the blocks'
  * work(): input_items[k] = stream k, doa_autocorrelate_input_span(noutput_items) samples; outputs
  * noutput_items items each).  cov_out and spectrum_out may be NULL: only the 2*num_targets floats

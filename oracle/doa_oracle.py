@@ -212,6 +212,17 @@ def music_null_spectrum(P_N: np.ndarray, A: np.ndarray) -> np.ndarray:
     return Q.real
 
 
+def music_db_from_q(Q: np.ndarray, precision: str = "f32") -> np.ndarray:
+    """lib/MUSIC_lin_array_impl.cc:140-142 on one item's null spectrum: out = 1.0/Q (a double division stored
+    to float), out_vec = 10*log10(out_vec/out_vec.max()).  An angle is at exactly 0 dB iff its ROUNDED
+    reciprocal equals the largest one; index_max / find_local_max then take the first such angle."""
+    rdt = _F32 if precision == "f32" else np.float64
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out = (1.0 / np.asarray(Q, dtype=rdt).astype(np.float64)).astype(rdt)
+        out = (out / out.max()).astype(rdt)
+        return (rdt(10.0) * np.log10(out)).astype(rdt)
+
+
 def music_lin_array(R_items: np.ndarray, norm_spacing: float, num_targets: int, num_ant_ele: int,
                     pspectrum_len: int, precision: str = "f32", return_parts: bool = False):
     """work() of doa::MUSIC_lin_array.  lib/MUSIC_lin_array_impl.cc:108-150.
@@ -231,10 +242,7 @@ def music_lin_array(R_items: np.ndarray, norm_spacing: float, num_targets: int, 
     for item in range(n):
         P_N = noise_projector(R_items[item], num_targets, N, precision)
         Q = music_null_spectrum(P_N, A).astype(rdt)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            out = (1.0 / Q.astype(np.float64)).astype(rdt)        # 1.0/Q_temp.real(): double divide -> float
-            out = (out / out.max()).astype(rdt)
-            spec[item] = (rdt(10.0) * np.log10(out)).astype(rdt)  # :142
+        spec[item] = music_db_from_q(Q, precision)
         Qs[item] = Q
         PNs[item] = P_N
     if return_parts:
@@ -409,6 +417,39 @@ def root_music_roots(P_N: np.ndarray, precision: str = "f32") -> np.ndarray:
     return w
 
 
+def root_music_select(roots: np.ndarray, norm_spacing: float, num_targets: int, precision: str = "f32") -> np.ndarray:
+    """The selection stage of work(), lib/rootMUSIC_linear_array_impl.cc:122-145, on a given set of
+    polynomial roots: dist = 1 - |z| (:122); keep dist > 0, strictly inside (:125-127); num_targets
+    times take index_min(dist), angle = 180 acos(arg(z) / (2 pi d)) / pi, mark the root used with inf
+    (:131-141) -- so with fewer interior roots than targets the remaining picks hit an inf entry,
+    arg(inf + 0i) = 0, i.e. 90 degrees; with none, index_min runs on an empty vector (an Armadillo
+    error: ValueError here); |arg / (2 pi d)| > 1 gives NaN -- then sort ascending (:144)."""
+    M = num_targets
+    d = float(_F32(norm_spacing))
+    rdt = _F32 if precision == "f32" else np.float64
+    roots = np.asarray(roots)
+    with np.errstate(invalid="ignore"):
+        dist = (rdt(1.0) - np.abs(roots)).astype(rdt)             # :122
+        inside = np.nonzero(dist > 0.0)[0]                        # :125
+    roots_in = roots[inside].copy()
+    dist_in = dist[inside].copy()
+    aoa = np.empty(M, dtype=_F32)
+    for ii in range(M):                                           # :131-141
+        if dist_in.shape[0] == 0:
+            raise ValueError("no root strictly inside the unit circle (Armadillo index_min error)")
+        k = int(np.argmin(dist_in))
+        z = roots_in[k]
+        if np.isinf(z.real):
+            ang = rdt(0.0)                                        # arg(inf+0i) = 0 -> 90 deg
+        else:
+            ang = rdt(np.angle(z))                                # std::arg in the root's type
+        with np.errstate(invalid="ignore"):
+            aoa[ii] = _F32(180.0 * np.arccos(float(ang) / (2 * np.pi * d)) / np.pi)
+        dist_in[k] = np.inf
+        roots_in[k] = complex(np.inf, 0.0)
+    return np.sort(aoa)                                           # :144
+
+
 def root_music(R_items: np.ndarray, norm_spacing: float, num_targets: int, num_ant_ele: int,
                precision: str = "f32") -> np.ndarray:
     """work() of doa::rootMUSIC_linear_array.  lib/rootMUSIC_linear_array_impl.cc:90-152.
@@ -416,31 +457,11 @@ def root_music(R_items: np.ndarray, norm_spacing: float, num_targets: int, num_a
     R_items = np.asarray(R_items)
     n = R_items.shape[0]
     N, M = num_ant_ele, num_targets
-    d = float(_F32(norm_spacing))
-    rdt = _F32 if precision == "f32" else np.float64
     out = np.empty((n, M), dtype=_F32)
     for item in range(n):
         P_N = noise_projector(R_items[item], M, N, precision)
         roots = root_music_roots(P_N, precision)
-        dist = (rdt(1.0) - np.abs(roots)).astype(rdt)             # :122
-        inside = np.nonzero(dist > 0.0)[0]                        # :125
-        roots_in = roots[inside].copy()
-        dist_in = dist[inside].copy()
-        aoa = np.empty(M, dtype=_F32)
-        for ii in range(M):                                       # :131-141
-            if dist_in.shape[0] == 0:
-                raise ValueError("no root strictly inside the unit circle (Armadillo index_min error)")
-            k = int(np.argmin(dist_in))
-            z = roots_in[k]
-            if np.isinf(z.real):
-                ang = rdt(0.0)                                    # arg(inf+0i) = 0 -> 90 deg
-            else:
-                ang = rdt(np.angle(z))                            # std::arg in the root's type
-            with np.errstate(invalid="ignore"):
-                aoa[ii] = _F32(180.0 * np.arccos(float(ang) / (2 * np.pi * d)) / np.pi)
-            dist_in[k] = np.inf
-            roots_in[k] = complex(np.inf, 0.0)
-        out[item] = np.sort(aoa)                                  # :144
+        out[item] = root_music_select(roots, norm_spacing, M, precision)
     return out
 
 

@@ -160,10 +160,10 @@ def test_music_scale_invariance_full_batch():
     assert np.abs(a - b).max() <= 2e-3      # power-of-two scaling: only the Jacobi stopping point may move
 
 
-def test_opt_in_block_kernels_match_oracle():
+def test_opt_in_evd_kernels_match_oracle():
     # kernel variants selected by environment switches that are read once per process (switches
-    # table): the 16-lanes-per-item block Jacobi for 4 < N <= 8 (DOA_EVD8_BLOCK=1) and the row-per-lane kernel for
-    # 8 < N <= 16 (DOA_EVD16_BLOCK=0), each in a child process against the fp64 oracle
+    # table): the row-per-lane kernel for 8 < N <= 16 (DOA_EVD16_BLOCK=0) and the 4-lanes-per-item group Jacobi for
+    # N <= 4 (DOA_EVD_KERNEL=1; the fused pipeline's EVD stage), each in a child process against the fp64 oracle
     import os
     import subprocess
     import sys
@@ -194,7 +194,7 @@ for name in sys.argv[1:]:
     assert np.abs(out - ref).max() <= 2e-4, (name, float(np.abs(out - ref).max()))
 print("ok")
 ''' % (os.path.join(here, "..", "gr-doa_amd", "python"), os.path.join(here, "..", "oracle"), here)
-    for env_add, names in (({"DOA_EVD8_BLOCK": "1"}, ["qa_music_aoa23", "five_ant"]),
+    for env_add, names in (({"DOA_EVD_KERNEL": "1"}, ["bench_cfg2", "grc_music_sim", "three_ant_fb"]),
                            ({"DOA_EVD16_BLOCK": "0"}, ["qa_music_aoa121", "twelve_ant"])):
         r = subprocess.run([sys.executable, "-c", code] + names, env=dict(os.environ, **env_add), capture_output=True,
                            text=True, timeout=300)

@@ -60,3 +60,118 @@ def test_root_music_create_rejects_bad_arguments():
     for args in [(0.5, 4, 4), (0.5, 0, 4), (0.7, 1, 4), (0.5, 1, 17)]:
         with pytest.raises(doa.DoaError):
             doa.rootMUSIC_linear_array(*args)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Selection edge cases of work() (reference lib/rootMUSIC_linear_array_impl.cc:122-141).
+#
+# Which of them a covariance item can reach: P_N = U_N U_N^H is a projector whatever the input, so the
+# polynomial's coefficients are conjugate-symmetric and its roots come in pairs (z, 1/conj(z)): unless a root
+# sits EXACTLY on the unit circle there are exactly N-1 >= num_targets of them strictly inside.  "Fewer than
+# num_targets interior roots" (-> 90 degree padding) therefore needs roots that are on the circle to the last
+# bit, where any two solvers (LAPACK cgeev included) disagree about which side the rounding error falls on; the
+# device solver keeps the pairing even on exactly rank-deficient data (first test below: always N-1 inside).
+# That branch is pinned at the level where it is well defined: the reference's selection rule
+# (oracle.root_music_select) applied to the very roots the device solver found must give the device's angles.
+# "No interior root at all" is reachable with non-finite input, and |arg z / (2 pi d)| > 1 with d < 0.5.
+# --------------------------------------------------------------------------------------------------------------
+def _steer(N, d, th):
+    loc = d * ((N - 1) / 2.0 - np.arange(N))
+    return np.exp(-2j * np.pi * np.cos(np.deg2rad(th)) * loc)
+
+
+def _rank_deficient_items(N, M, d, thetas, n):
+    items = []
+    for k in range(n):
+        A = np.stack([_steer(N, d, t + 0.37 * k) for t in thetas], axis=1)
+        p = np.diag(1.0 + 0.1 * np.arange(M) + 0.01 * k)
+        items.append((A @ p @ A.conj().T).astype(np.complex64).reshape(-1, order="F"))   # exactly rank M
+    return np.stack(items)
+
+
+@pytest.mark.parametrize("N,M,d,thetas", [(3, 2, 0.5, (60., 110.)), (4, 2, 0.5, (50., 120.)), (4, 3, 0.5, (40., 90., 130.)),
+                                           (4, 2, 0.44, (30., 123.)), (5, 3, 0.5, (40., 80., 120.)), (3, 2, 0.3, (20., 160.)),
+                                           (2, 1, 0.3, (15.,)), (8, 4, 0.35, (10., 60., 100., 170.))])
+def test_root_selection_rule_on_the_solvers_own_roots(N, M, d, thetas):
+    R = _rank_deficient_items(N, M, d, thetas, 40)                 # double roots on the unit circle: the hard case
+    rng = np.random.default_rng(N * 100 + M)
+    noisy = rng.standard_normal((24, N, N)) + 1j * rng.standard_normal((24, N, N))
+    noisy = np.einsum("kab,kcb->kac", noisy, noisy.conj()) / N    # full-rank Hermitian PSD: roots anywhere
+    R = np.concatenate([R, noisy.transpose(0, 2, 1).reshape(24, -1).astype(np.complex64)])
+    blk = doa.rootMUSIC_linear_array(d, M, N)
+    ang, roots, status = blk.debug(R)
+    out = np.empty_like(ang)
+    assert blk.work(R.shape[0], [R], [out]) == R.shape[0] and np.array_equal(out, ang, equal_nan=True)
+    assert not status.any()
+    inside = (1.0 - np.abs(roots) > 0.0).sum(axis=1)
+    assert np.all(inside == N - 1), np.bincount(inside)            # conjugate-reciprocal pairs, none on the circle
+    for i in range(R.shape[0]):
+        want = oracle.root_music_select(roots[i], d, M, "f64")     # :122-145 on the device's roots
+        assert np.array_equal(np.isnan(want), np.isnan(ang[i])), (i, want, ang[i])
+        ok = ~np.isnan(want)
+        assert np.all(np.abs(want[ok] - ang[i][ok]) <= 1e-5), (i, want, ang[i])
+        fin = ang[i][~np.isnan(ang[i])]
+        assert np.all(np.diff(fin) >= 0) and (np.isnan(ang[i, len(fin):]).all())    # ascending, NaN last (:144)
+
+
+def test_root_angle_outside_the_visible_region_is_nan():
+    # N = 2, one source: P_N = v v^H with v = [cos a, sin a e^{jb}] gives u_1 = cos a sin a e^{jb}; the interior root
+    # of u_1 z^2 + z + conj(u_1) has |arg z| = |pi - |b|| or so, and with d = 0.3 every |arg z| > 2 pi d = 1.885 has
+    # no real angle: acos(> 1) is NaN in the reference (:136) and here.  The sweep over b crosses that border.
+    d, N, M = 0.3, 2, 1
+    items = []
+    for a in (0.3, 0.7, 1.2):
+        for b in np.linspace(-3.0, 3.0, 13):
+            v = np.array([np.cos(a), np.sin(a) * np.exp(1j * b)])
+            s = np.array([-np.conj(v[1]), np.conj(v[0])])         # signal vector, orthogonal to v
+            R = 5.0 * np.outer(s, s.conj()) + 0.01 * np.outer(v, v.conj())
+            items.append(R.astype(np.complex64).reshape(-1, order="F"))
+    R = np.stack(items)
+    blk = doa.rootMUSIC_linear_array(d, M, N)
+    got = np.empty((len(items), M), np.float32)
+    assert blk.work(len(items), [R], [got]) == len(items)
+    a64 = oracle.root_music(R, d, M, N, "f64")
+    assert np.array_equal(np.isnan(a64), np.isnan(got))
+    assert 5 <= np.isnan(got).sum() <= len(items) - 5             # both outcomes are exercised
+    ok = ~np.isnan(a64)
+    assert np.abs(a64[ok] - got[ok]).max() <= 1e-3
+
+
+def test_root_music_no_interior_root_is_an_error_and_spares_the_good_rows():
+    # The reference calls index_min on an empty vector here (an Armadillo exception, :131-133).  Reachable with a
+    # non-finite item: every comparison dist > 0 fails.  The call reports DOA_ERR_NUMERIC, the bad rows are NaN, and
+    # the good rows of the same call are the same as without the bad ones.
+    c, x = make_input("bench_cfg3")
+    N, M, n = c["N"], c["M"], c["n"]
+    R = oracle.autocorrelate(x, c["K"], c["ovl"], c["fb"], n)
+    good = np.empty((n, M), np.float32)
+    blk = doa.rootMUSIC_linear_array(c["d"], M, N)
+    assert blk.work(n, [R], [good]) == n
+    Rb = R.copy()
+    bad_rows = [1, n - 2]
+    Rb[bad_rows[0], :] = np.nan
+    Rb[bad_rows[1], 5] = np.inf
+    out = np.full((n, M), -1.0, np.float32)
+    with pytest.raises(doa.DoaError) as ei:
+        blk.work(n, [Rb], [out])
+    assert ei.value.status == -5 and "no root strictly inside" in str(ei.value)
+    assert np.isnan(out[bad_rows]).all()
+    keep = [i for i in range(n) if i not in bad_rows]
+    assert np.array_equal(out[keep], good[keep])
+    ang, roots, status = blk.debug(Rb)
+    assert status[bad_rows].all() and not status[keep].any()
+    for i in bad_rows:                                            # the oracle (= the reference's rule) raises there too
+        with pytest.raises((ValueError, np.linalg.LinAlgError)):
+            oracle.root_music(Rb[i:i + 1], c["d"], M, N, "f64")
+
+
+def test_root_selection_padding_rule_of_the_reference():
+    # fewer than num_targets interior roots (not reachable from a covariance item, see the note above): the rule the
+    # device code mirrors -- remaining picks hit an "inf" entry, arg(inf + 0i) = 0, i.e. 90 degrees -- stated once on
+    # explicit root sets so that a change of either side shows up
+    roots = np.array([0.5 * np.exp(1j * 1.0), 2.0 * np.exp(1j * 1.0), 1.5, 1.25 * np.exp(-0.3j)])
+    got = oracle.root_music_select(roots, 0.5, 3, "f64")
+    want = np.sort(np.array([np.degrees(np.arccos(1.0 / np.pi)), 90.0, 90.0], np.float32))
+    assert np.allclose(got, want, atol=1e-5)
+    with pytest.raises(ValueError):
+        oracle.root_music_select(np.array([1.5, 2.0 + 1j]), 0.5, 1, "f64")

@@ -70,12 +70,15 @@ if "root" in args.stages:
     root_blk = doa.rootMUSIC_linear_array(0.5, M, N)
     ang = [torch.empty((B, M), dtype=torch.float32, device="cuda") for _ in range(nb)]
     res["root_us"] = timeit(lambda i: root_blk.work_dev(B, cov[i % nb].data_ptr(), ang[i % nb].data_ptr(), st))
-skip_later = os.environ.pop("DOA_PIPE_SKIP", None)      # populate every intermediate with real data first
+skip_later = os.environ.pop("DOA_PIPE_SKIP", None)      # "cov", "evd", "scan" (comma separated): stages to drop AFTER every intermediate holds real data
+def apply_skip(p, on):
+    sk = skip_later or ""
+    p.set_stages(cov=not (on and "cov" in sk), evd=not (on and "evd" in sk), scan=not (on and "scan" in sk))
 if "pipe" in args.stages:
     for i in range(nb):
         pipe.work_dev(B, ptrs[i % nb], cov[i % nb].data_ptr(), spec[i % nb].data_ptr(), mx[i % nb].data_ptr(), am[i % nb].data_ptr(), st)
     torch.cuda.synchronize()
-    if skip_later: os.environ["DOA_PIPE_SKIP"] = skip_later
+    apply_skip(pipe, True)
     res["pipe_us"] = timeit(lambda i: pipe.work_dev(B, ptrs[i % nb], cov[i % nb].data_ptr(), spec[i % nb].data_ptr(),
                                                     mx[i % nb].data_ptr(), am[i % nb].data_ptr(), st))
     res["snapshots_per_s"] = B / res["pipe_us"][0] * 1e6
@@ -90,9 +93,8 @@ if "mpipe" in args.stages:
             pipes[k].work_dev(B, ptrs[i % nb], cov[i % nb].data_ptr(), spec[i % nb].data_ptr(), mx[i % nb].data_ptr(),
                               am[i % nb].data_ptr(), sts[k])
     import time
-    os.environ.pop("DOA_PIPE_SKIP", None)
     run(2 * S * nb); torch.cuda.synchronize()          # real data in every workspace
-    if skip_later: os.environ["DOA_PIPE_SKIP"] = skip_later
+    for p_ in pipes: apply_skip(p_, True)
     run(20); torch.cuda.synchronize()
     ts = []
     for r in range(5):
