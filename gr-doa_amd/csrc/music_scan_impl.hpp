@@ -51,23 +51,31 @@ __device__ __forceinline__ float db_from_ratio(float out, float mx, float inv_mx
     return db;
 }
 
-// Lean form, from Q itself and its item minimum mn (a normal positive float): max(out) = 1/mn.
+// Lean form, from Q itself and its item minimum mn (a normal positive float): max(out) = RN(1/mn) =: mx, and
+// because RN(1/q) is monotone in q the tie set {q : RN(1/q) == mx} is the interval [mn, q_hi] of floats, q_hi at
+// most a few ulp above mn (1 ulp of q moves 1/q by 0.5..2 ulp of the result).  q_hi is found once per item
+// (wave-uniform: IEEE divisions on mn + 1 and + 2 ulp -- two floats 1 ulp apart have reciprocals >= 0.5 ulp apart,
+// so a third cannot share the rounded value); per angle the whole rule is then ONE compare:
+//     tie = (q <= q_hi),   dB = tie ? 0 : -10 log10(2) log2(max(q (1/mn), 1 + 2^-23)).
+// The clamp keeps a non-tied angle strictly negative whatever v_rcp_f32 / the product round to (its true value
+// there is -2.6e-7 dB times a small integer; the clamp gives -5.2e-7: the only place where the fast path is not
+// within v_log_f32's own error of the reference's float arithmetic, and 1e-6 dB below anyone's tolerance).
 struct LeanNorm {
-    float inv_mn, thr, mx;
-    __device__ __forceinline__ explicit LeanNorm(float mn)
-        : inv_mn(__builtin_amdgcn_rcpf(mn)), thr(mn * 1.000001f), mx(1.0f / mn) {}
-    // dB of one angle; tie = this angle holds the maximum.  Q > thr cannot tie (its reciprocal is > 7 ulp away)
-    // and has Q * (1/mn) >= 1 + 8e-7, i.e. a strictly negative dB through the fast path.
+    float inv_mn, q_hi;
+    __device__ __forceinline__ explicit LeanNorm(float mn) : inv_mn(__builtin_amdgcn_rcpf(mn)), q_hi(mn)
+    {
+        const float mx = 1.0f / mn;
+#pragma unroll
+        for (int k = 1; k <= 2; k++) {
+            const float qk = __int_as_float(__float_as_int(mn) + k);
+            q_hi = (1.0f / qk == mx) ? qk : q_hi;
+        }
+    }
     __device__ __forceinline__ float db(float q, bool &tie) const
     {
-        float d = -kDbPerLog2 * __log2f(q * inv_mn);
-        tie = false;
-        if (q <= thr) {                                  // rare: the minimum itself and its near-ties
-            const float o = 1.0f / q;
-            tie = (o == mx);
-            d = tie ? 0.0f : kDbPerUnit * (o / mx - 1.0f);
-        }
-        return d;
+        tie = (q <= q_hi);
+        const float d = -kDbPerLog2 * __log2f(fmaxf(q * inv_mn, 1.00000011920928955f));
+        return tie ? 0.0f : d;
     }
 };
 __device__ __forceinline__ bool lean_norm_ok(float mn) { return (mn >= 1.2e-38f) && (mn < INFINITY); }

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of one round on the GPU box into gpurun_out/prof_<tag>/ (scratch);
+# tools/summarize_profiles.py <tag> then copies the judged summaries into profiles/ (tracked).
+# Every rocprofv3 command has the program itself directly behind `--` (no env/bash hop), and the PMC passes
+# are separate from the kernel-trace passes.   usage (on the box):  bash tools/profile_round.sh r02
+set -u
+tag=${1:-r02}
+out=gpurun_out/prof_$tag
+mkdir -p $out
+export TMPDIR=/tmp
+run() {   # name, rocprof args..., -- program...
+    name=$1; shift
+    echo "$name: rocprofv3 $*" >> $out/commands.txt
+    rocprofv3 "$@" > $out/$name.log 2>&1 || echo "$name FAILED rc=$?" >> $out/commands.txt
+}
+T="--kernel-trace --stats --output-format csv"
+BENCH_SERIAL="python3 bench.py --steps 200 --warmup 20 --streams 1 --no-cpu-baseline --no-scan-roofline"
+BENCH_OVL="python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-scan-roofline"
+SCAN_L="python3 tools/profile_scan.py --batch 262144 --reps 40"
+SCAN_B="python3 tools/profile_scan.py --batch 4096 --reps 200"
+run trace_serial  $T -d $out/trace_serial  -- $BENCH_SERIAL
+run trace_overlap $T -d $out/trace_overlap -- $BENCH_OVL
+run trace_scan262144 $T -d $out/trace_scan262144 -- $SCAN_L
+run trace_scan4096   $T -d $out/trace_scan4096   -- $SCAN_B
+for ctr in FETCH_SIZE WRITE_SIZE; do
+    run pmc_${ctr}_bench4096    --pmc $ctr --output-format csv -d $out/pmc_${ctr}_bench4096    -- python3 bench.py --steps 40 --warmup 5 --streams 1 --no-cpu-baseline --no-scan-roofline
+    run pmc_${ctr}_scan262144   --pmc $ctr --output-format csv -d $out/pmc_${ctr}_scan262144   -- python3 tools/profile_scan.py --batch 262144 --reps 12
+done
+# the other BASELINE.json configs (parity-test cases, not bench lines)
+run trace_cfg3_root   $T -d $out/trace_cfg3_root   -- python3 tools/bench_kernels.py --M 2 --stages cov,root --reps 40
+run trace_cfg4_n16    $T -d $out/trace_cfg4_n16    -- python3 tools/bench_kernels.py --N 16 --M 3 --P 4096 --stages pipe --reps 20
+run trace_flowgraph   $T -d $out/trace_flowgraph   -- python3 tools/bench_kernels.py --M 2 --K 2048 --ovl 512 --fb 1 --stages pipe --reps 40
+run trace_n8          $T -d $out/trace_n8          -- python3 tools/bench_kernels.py --N 8 --M 2 --stages pipe --reps 40
+for ctr in FETCH_SIZE WRITE_SIZE; do
+    run pmc_${ctr}_cfg4 --pmc $ctr --output-format csv -d $out/pmc_${ctr}_cfg4 -- python3 tools/bench_kernels.py --N 16 --M 3 --P 4096 --stages pipe --reps 6
+done
+cat $out/commands.txt
