@@ -596,7 +596,10 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
     static const int lean = [] { const char *e = getenv("DOA_SCAN_LEAN"); return e ? atoi(e) : 1; }();
     if (lean && aligned && pk.val && pk.M >= 1 && !q && n_ant == N && (P == 256 || P == 512 || P == 1024)) {
         int lb = (n_items + waves_per_block - 1) / waves_per_block;
-        static const int lwpc = [] { const char *e = getenv("DOA_SCAN_LEAN_WAVES_PER_CU"); return e ? atoi(e) : 8; }();
+        // 12 waves per CU: the kernel is vector-pipe bound at large batches (compute without stores 219 us, stores
+        // without compute 193 us, both 268 us per 262144 items on one box; 8 waves: 247 / 210 / 282), so a third wave
+        // per SIMD to fill the DPP-reduction and v_log latencies pays; 16 measured no better
+        static const int lwpc = [] { const char *e = getenv("DOA_SCAN_LEAN_WAVES_PER_CU"); return e ? atoi(e) : 12; }();
         if (lb > cu_count() * lwpc / waves_per_block) lb = cu_count() * lwpc / waves_per_block;
         dim3 lgrid(lb);
 #define DOA_LEAN_LAUNCH(CH_, MULTI_)                                                                              \
