@@ -66,20 +66,8 @@ __global__ __launch_bounds__(256) void find_local_max_kernel(const float *__rest
     peak_pick<CH>(v, lane, L, M, xaxis, out_val + (size_t)item * M, out_loc + (size_t)item * M);
 }
 
-// Long or oddly sized vectors (any 1 <= L <= 4096, any alignment): one wave per vector, 64 consecutive positions
-// per step (position p = 64 k + lane), nothing of the vector kept in registers.  The three-way sign of every
-// first difference is two compares whose results are wave masks in SGPR pairs, in position order, so the
-// reference's steps become scalar bit arithmetic:
-//   * flats (sign 0; a NaN difference counts as one) take the sign of the next non-zero difference to their
-//     right: groups are walked from the last to the first, the sign at the start of the group to the right is
-//     a carried bit, and inside a group the fill is a 6-step Kogge-Stone propagation on the 64-bit mask
-//     (only groups that contain a flat pay for it);
-//   * lane k keeps the resolved "negative" mask of group k; all peak masks are then one vector expression,
-//     peak[k] = neg[k] & ~((neg[k] << 1) | (neg[k-1] >> 63));
-//   * the top-M are M rounds of (every lane scans the set bits of its own group, re-reading those values;
-//     wave arg-max); the fill rule, index_max and the output ordering are those of peak_pick.
-// ~1000 instructions and ~40 VGPRs per vector at L = 4096, where the register-resident CH = 16 kernel executes
-// ~6500 with 230 VGPRs.
+// Long or oddly sized vectors (any 1 <= L <= 4096, any alignment): peak_pick_stream (peak_device.hpp) straight
+// out of global memory.
 __global__ __launch_bounds__(256) void find_local_max_stream_kernel(const float *__restrict__ in, const float *__restrict__ xaxis,
                                                                     float *__restrict__ out_val, float *__restrict__ out_loc,
                                                                     int L, int M, int n_items)
@@ -88,104 +76,7 @@ __global__ __launch_bounds__(256) void find_local_max_stream_kernel(const float 
     const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
     if (item >= n_items) return;
     const float *v_in = in + (size_t)item * L;
-    float *out_val_item = out_val + (size_t)item * M, *out_loc_item = out_loc + (size_t)item * M;
-    const int G = (L + 63) >> 6;                         // groups of 64 positions (<= 64)
-
-    // arma index_max (op_max::direct_max): first occurrence of the maximum; NaN and -inf never win; none -> 0
-    float mv = 0.f;
-    int mi = INT_MAX;
-    unsigned long long neg_mine = 0ull;                  // lane k: resolved "sign == -1" mask of group k
-    {
-        unsigned long long carry_neg = 0ull;             // resolved sign at the first position of the group to the right (0: +1)
-        float above_first = 0.f;                         // value at the first position of the group to the right
-        constexpr int U = 8;                             // groups per batch: U loads in flight per lane before any is consumed
-        for (int kb = ((G - 1) / U) * U; kb >= 0; kb -= U) {
-            float vb[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int p = 64 * (kb + u) + lane;
-                vb[u] = (p < L) ? v_in[p] : 0.f;
-            }
-#pragma unroll
-            for (int u = U - 1; u >= 0; u--) {
-                const int k = kb + u;
-                if (k >= G) continue;                    // wave-uniform
-                const int p = 64 * k + lane;
-                const bool inb = p < L, has_diff = p + 1 < L;
-                const float v = vb[u];
-                // next value: lane+1 of this group; lane 63: the first value of the group to the right
-                float nx = __shfl_down(v, 1, kWave);
-                if (lane == kWave - 1) nx = above_first;
-                above_first = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-                // descending walk: ">=" lets the lower position win a tie, i.e. the first occurrence overall
-                if (inb && v > -INFINITY && (mi == INT_MAX || v >= mv)) { mv = v; mi = p; }
-                const unsigned long long neg = __builtin_amdgcn_ballot_w64(has_diff && nx < v);
-                const unsigned long long pos = __builtin_amdgcn_ballot_w64(has_diff ? (nx > v) : true);   // past the last difference: +1
-                const unsigned long long flat = ~(neg | pos);
-                unsigned long long res = neg;
-                if (flat != 0ull) {
-                    unsigned long long prop = flat;
-                    res |= prop & (carry_neg << 63);
-#pragma unroll
-                    for (int sh = 1; sh < 64; sh <<= 1) {
-                        res |= (res >> sh) & prop;
-                        prop &= prop >> sh;
-                    }
-                }
-                carry_neg = res & 1ull;
-                if (lane == k) neg_mine = res;
-            }
-        }
-    }
-    wave_argbest(mv, mi);
-    const int idx_max = (mi == INT_MAX) ? 0 : mi;
-
-    int sel_idx = INT_MAX;
-    float sel_val = 0.f;
-    int n_valid = 0, best_list_pos = 0;
-    if (M > 1) {
-        // peaks: s[p-1] == +1 and s[p] == -1, 1 <= p <= L-2 (positions >= L-1 carry +1, so they never qualify)
-        const unsigned long long below = __shfl_up(neg_mine, 1, kWave);
-        unsigned long long pk = neg_mine & ~((neg_mine << 1) | ((lane > 0) ? (below >> 63) : 0ull));
-        if (lane == 0) pk &= ~1ull;
-        const unsigned long long pk_all = pk;
-        n_valid = wave_sum_int(__builtin_popcountll(pk));
-        const int rounds = (n_valid < M) ? n_valid : M;
-        for (int r = 0; r < rounds; r++) {
-            float bv = 0.f;
-            int bi = INT_MAX;
-            for (unsigned long long m = pk; m != 0ull; m &= m - 1ull) {
-                const int pp = 64 * lane + (int)__builtin_ctzll(m);
-                const float val = v_in[pp];
-                if (cand_better(val, pp, bv, bi)) { bv = val; bi = pp; }
-            }
-            wave_argbest(bv, bi);
-            if (r == 0) {
-                // position of the best peak inside the ascending peak list (= #peaks before it)
-                const int rel = bi - 64 * lane;
-                const unsigned long long lower = (rel >= 64) ? ~0ull : ((rel <= 0) ? 0ull : ((1ull << rel) - 1ull));
-                best_list_pos = wave_sum_int(__builtin_popcountll(pk_all & lower));
-            }
-            if (bi != INT_MAX && (bi >> 6) == lane) pk &= ~(1ull << (bi & 63));
-            if (lane == r) { sel_idx = bi; sel_val = bv; }
-        }
-    }
-    const int fill_idx = (M == 1 || n_valid == 0) ? idx_max : best_list_pos;   // reference quirk for 0 < n_valid < M (:153,160)
-    const float fill_val = v_in[fill_idx];
-    if (lane < M) {
-        int idx;
-        float val;
-        if (M > 1 && lane < n_valid) { idx = sel_idx; val = sel_val; }
-        else { idx = fill_idx; val = fill_val; }
-        const float x = xaxis[idx];
-        out_val_item[lane] = val;
-        int rank = 0;                                    // descending sort of the M locations
-        for (int k = 0; k < M; k++) {
-            const float xk = __shfl(x, k, kWave);
-            rank += (xk > x || (xk == x && k < lane)) ? 1 : 0;
-        }
-        out_loc_item[rank] = x;
-    }
+    peak_pick_stream([&](int p) { return v_in[p]; }, L, M, xaxis, out_val + (size_t)item * M, out_loc + (size_t)item * M, lane);
 }
 
 // Literal walk of the reference's steps, one thread per vector (any L >= 1).  `scratch` holds L

@@ -529,6 +529,90 @@ __global__ __launch_bounds__(256) void music_scan_stream_kernel(const T *__restr
     }
 }
 
+// Long spectra with the peak pick fused (2048 < P <= 4096, P % 64 == 0, double): one wave per item, one angle per
+// lane per step (position p = 64 g + lane), the item's row staged in LDS (16 KiB per wave, 64 KiB per workgroup:
+// two workgroups per CU).  Pass 1 leaves Q as float in the LDS row and finds its minimum; pass 2 turns the row into
+// dB in place and writes it to HBM ONCE; find_local_max then runs on the LDS row (peak_pick_stream, the same masks-in-
+// SGPRs code as the stand-alone K5).  The two-launch form this replaces (music_scan_stream_kernel parks Q in the
+// output row, then find_local_max_stream_kernel reads the row back) moves the 4P-byte row through HBM four times:
+// write, read, write, read.  Rolled loops: ~100 VGPRs where a register-resident row plus peak_pick<16> needs 511.
+template <int N, typename T>
+__global__ __launch_bounds__(256) void music_scan_peak_long_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
+                                                                   float *__restrict__ spec, int P, int n_items, int n_ant,
+                                                                   const float *__restrict__ xaxis, float *__restrict__ pk_val,
+                                                                   float *__restrict__ pk_loc, int M)
+{
+    constexpr int PMAX = 4096;
+    __shared__ float rows[4][PMAX];               // 64 KiB per workgroup: two workgroups (8 waves) per CU; 10 waves per CU
+                                                  // as five 2-wave workgroups measured 12 % slower
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = threadIdx.x / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + wib);
+    const int n_waves = gridDim.x * (blockDim.x / kWave);
+    const int rec = 2 * n_ant;
+    const int G = P >> 6;
+    float *lrow = rows[wib];
+    for (int item = wave; item < n_items; item += n_waves) {
+        T c[2 * N];
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) c[k] = (k < rec - 1) ? coef[(size_t)item * rec + k] : (T)0;
+        // pass 1: Q (float) into the LDS row, and its minimum
+        float mn = INFINITY;
+        // (table entries of UZ steps are requested before the first Horner starts: with two waves per SIMD the L2
+        // latency of a dependent load per step would otherwise be most of the pass)
+        constexpr int UZ = 8;
+        for (int g0 = 0; g0 < G; g0 += UZ) {
+            T zr[UZ], zi[UZ];
+#pragma unroll
+            for (int u = 0; u < UZ; u++) {
+                const int i = min(64 * (g0 + u) + lane, P - 1);
+                zr[u] = ztab[2 * (size_t)i]; zi[u] = ztab[2 * (size_t)i + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < UZ; u++) {
+                if (g0 + u < G) {
+                    const int i = 64 * (g0 + u) + lane;
+                    const float q = (float)null_spectrum<N, T>(c, zr[u], zi[u]);
+                    lrow[i] = q;
+                    mn = fminf(mn, q);
+                }
+            }
+        }
+        mn = wave_allreduce_min(mn);
+        float *grow = spec + (size_t)item * P;
+        // pass 2: dB in place (each lane rewrites exactly the positions it wrote), one HBM write of the row
+        if (lean_norm_ok(mn)) {
+            const LeanNorm nrm(mn);
+#pragma unroll 4
+            for (int g = 0; g < G; g++) {
+                const int i = 64 * g + lane;
+                bool tie;
+                const float d = nrm.db(lrow[i], tie);
+                lrow[i] = d;
+                __builtin_nontemporal_store(d, grow + i);
+            }
+        } else {
+            float mx = -INFINITY;
+#pragma unroll 4
+            for (int g = 0; g < G; g++) mx = fmaxf(mx, 1.0f / lrow[64 * g + lane]);
+            mx = wave_allreduce_max(mx);
+            const float inv_mx = __builtin_amdgcn_rcpf(mx);
+#pragma unroll 4
+            for (int g = 0; g < G; g++) {
+                const int i = 64 * g + lane;
+                const float d = db_from_ratio(1.0f / lrow[i], mx, inv_mx);
+                lrow[i] = d;
+                __builtin_nontemporal_store(d, grow + i);
+            }
+        }
+        // the row was written lane by lane; the peak pick reads it across lanes (same wave: LDS operations of one wave
+        // complete in order, the fence only keeps the compiler from moving them)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        peak_pick_stream([&](int p) { return lrow[p]; }, P, M, xaxis, pk_val + (size_t)item * M, pk_loc + (size_t)item * M, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
 // Any P: one wave per item, one angle per lane per step, two passes (max, then write).
 template <int N, typename T>
 __global__ __launch_bounds__(256) void music_scan_generic_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
@@ -623,6 +707,16 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
     // per-SIMD kernel (135 us per 4096 items at N = 16); the streaming scan (~30 us) followed by the stand-alone
     // find_local_max kernel (~47 us) is faster, so the peak pick is left to the caller there (returns false).
     if (stream_on && aligned && P > 2048 && sizeof(T) == 8 && !q) {
+        // with the peak pick wanted (the pipeline) and P a multiple of 64 up to 4096: scan + K5 in one launch, the row
+        // written once (DOA_SCAN_LONG_FUSED=0: the two-launch form)
+        static const int long_fused = [] { const char *e = getenv("DOA_SCAN_LONG_FUSED"); return e ? atoi(e) : 1; }();
+        if (long_fused && pk.val && pk.M >= 1 && P % 64 == 0 && P <= 4096) {
+            int fb = (n_items + waves_per_block - 1) / waves_per_block;
+            if (fb > cu_count() * 2) fb = cu_count() * 2;                 // 64 KiB of LDS per workgroup: two per CU
+            hipLaunchKernelGGL((music_scan_peak_long_kernel<N, T>), dim3(fb), block, 0, st, co, z, sp, P, n_items, n_ant,
+                               pk.xaxis, pk.val, pk.loc, pk.M);
+            return true;
+        }
         int sb = (n_items + waves_per_block - 1) / waves_per_block;
         if (sb > cu_count() * 16 / waves_per_block) sb = cu_count() * 16 / waves_per_block;
         hipLaunchKernelGGL((music_scan_stream_kernel<N, T>), dim3(sb), block, 0, st, co, z, sp, P, n_items, n_ant);
