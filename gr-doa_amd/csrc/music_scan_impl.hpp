@@ -320,7 +320,7 @@ __device__ __forceinline__ void lean_scan_item(const T (&c)[2 * N], const T (&zr
                 store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
                                make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
             }
-            peak_pick<CH>(qf, lane, P, M, xs, pk_val_item, pk_loc_item);
+            if (pk_val_item) peak_pick<CH>(qf, lane, P, M, xs, pk_val_item, pk_loc_item);
         } else {
             int pos = INT_MAX;
 #pragma unroll
@@ -338,7 +338,7 @@ __device__ __forceinline__ void lean_scan_item(const T (&c)[2 * N], const T (&zr
             }
             // (the minimum itself always ties, so pos is a valid angle; the clamp only keeps a broken invariant from
             // turning into a wild address)
-            if (lane == 0) { pk_val_item[0] = 0.0f; pk_loc_item[0] = xs[min(pos, P - 1)]; }
+            if (lane == 0 && pk_val_item) { pk_val_item[0] = 0.0f; pk_loc_item[0] = xs[min(pos, P - 1)]; }
         }
     } else {
         lean_scan_item_irregular<N, CH, T, MULTI>(c, qf, ztab, row, xs, pk_val_item, pk_loc_item, M, lane);
@@ -368,7 +368,7 @@ __device__ __forceinline__ void lean_scan_item_irregular(const T (&c)[2 * N], fl
             store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
                            make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
         }
-        peak_pick<CH>(qf, lane, P, M, xs, pk_val_item, pk_loc_item);
+        if (pk_val_item) peak_pick<CH>(qf, lane, P, M, xs, pk_val_item, pk_loc_item);
         return;
     }
     float bv = 0.f;
@@ -387,7 +387,7 @@ __device__ __forceinline__ void lean_scan_item_irregular(const T (&c)[2 * N], fl
         }
     wave_argbest(bv, bi);
     v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), 0));
-    if (lane == 0) {
+    if (lane == 0 && pk_val_item) {
         pk_val_item[0] = (bi == INT_MAX) ? v0 : bv;
         pk_loc_item[0] = xs[(bi == INT_MAX) ? 0 : bi];
     }
@@ -414,7 +414,9 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
 {
     constexpr int P = 256 * CH;
     __shared__ float xs[P];
-    for (int i = threadIdx.x; i < P; i += blockDim.x) xs[i] = xaxis[i];
+    if (xaxis) {                                      // (pk_val == nullptr: spectrum only, the stand-alone MUSIC block)
+        for (int i = threadIdx.x; i < P; i += blockDim.x) xs[i] = xaxis[i];
+    }
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
@@ -436,8 +438,9 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
 #pragma unroll
             for (int k = 0; k < 2 * N; k++) c_next[k] = coef[(size_t)nxt * (2 * N) + k];
         }
-        lean_scan_item<N, CH, T, MULTI>(c, zr, zi, ztab, spec + (size_t)item * P, xs, pk_val + (size_t)item * M,
-                                        pk_loc + (size_t)item * M, M, lane);
+        lean_scan_item<N, CH, T, MULTI>(c, zr, zi, ztab, spec + (size_t)item * P, xs,
+                                        pk_val ? pk_val + (size_t)item * M : nullptr,
+                                        pk_val ? pk_loc + (size_t)item * M : nullptr, M, lane);
     }
 }
 
@@ -678,7 +681,9 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
     dim3 grid(blocks), block(waves_per_block * kWave);
     // the lean benchmark-shape kernel (see music_scan_peak1_kernel)
     static const int lean = [] { const char *e = getenv("DOA_SCAN_LEAN"); return e ? atoi(e) : 1; }();
-    if (lean && aligned && pk.val && pk.M >= 1 && !q && n_ant == N && (P == 256 || P == 512 || P == 1024)) {
+    // (also without a peak pick -- the stand-alone MUSIC_lin_array block -- so that block and pipeline produce the
+    // same spectrum bit for bit: same kernel, same arithmetic)
+    if (lean && aligned && !q && n_ant == N && (P == 256 || P == 512 || P == 1024)) {
         int lb = (n_items + waves_per_block - 1) / waves_per_block;
         // 12 waves per CU: the kernel is vector-pipe bound at large batches (compute without stores 219 us, stores
         // without compute 193 us, both 268 us per 262144 items on one box; 8 waves: 247 / 210 / 282), so a third wave
@@ -689,7 +694,7 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
 #define DOA_LEAN_LAUNCH(CH_, MULTI_)                                                                              \
     hipLaunchKernelGGL((music_scan_peak1_kernel<N, CH_, T, MULTI_>), lgrid, block, 0, st, co, z, sp, n_items, pk.xaxis, \
                        pk.val, pk.loc, pk.M)
-        if (pk.M == 1) {
+        if (pk.M <= 1) {
             if (P == 256) DOA_LEAN_LAUNCH(1, false);
             else if (P == 512) DOA_LEAN_LAUNCH(2, false);
             else DOA_LEAN_LAUNCH(4, false);
@@ -699,7 +704,7 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
             else DOA_LEAN_LAUNCH(4, true);
         }
 #undef DOA_LEAN_LAUNCH
-        return true;
+        return pk.val != nullptr;
     }
     // long spectra without diagnostics and without a fused peak pick: the streaming two-pass kernel
     static const int stream_on = [] { const char *e = getenv("DOA_SCAN_STREAM"); return e ? atoi(e) : 1; }();

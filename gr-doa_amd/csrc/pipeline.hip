@@ -31,6 +31,7 @@ struct doa_music_pipeline {
     hipStream_t hst[2] = {nullptr, nullptr};
     doa::DevBuf d_in[2], d_res;
     doa::DevBuf d_work[2];          // K1's piece sums (overlapping windows), one per copy/compute lane
+    doa::PinnedBuf h_stage;         // scheduler-sized calls: one page-locked staging buffer, one copy each way
 };
 
 // K1 -> EVD -> scan (+ peak) for n items on `st`; coefficient records at item offset `coef_off` of the
@@ -110,7 +111,7 @@ void doa_music_pipeline_destroy(doa_music_pipeline_t *h)
     h->music.release();
     h->peaks.release();
     h->d_cov.release(); h->d_coef.release(); h->d_spec.release(); h->d_scratch.release(); h->d_gain.release();
-    h->d_res.release();
+    h->d_res.release(); h->h_stage.release();
     for (auto &b : h->d_work) b.release();
     for (auto &b : h->d_in) b.release();
     for (auto st : h->hst)
@@ -185,10 +186,60 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
     if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     for (auto &st : h->hst)
         if (!st) DOA_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const size_t nonoverlap = (size_t)(h->K - h->ovl);
+    // Scheduler-sized calls (a GNU Radio work() hands over a few to a few hundred items): the fixed costs are what
+    // counts -- N pageable host-to-device copies, up to four copies back and two stream synchronisations.  Below
+    // kSmallCallBytes of input the window of every stream is packed into ONE page-locked staging buffer (the same
+    // bytes the driver's pageable path would stage, minus its per-copy set-up), crosses PCIe as ONE transfer, and the
+    // angles (+ the optional covariances / spectra) come back as ONE transfer through the same buffer.  Measured: 8 items
+    // 105 -> 53 us per call, 64 items 151 -> 116 us; from 8 MiB up the host-side packing costs more than it saves.
+    {
+        static const size_t kSmallCallBytes = [] { const char *e = getenv("DOA_PIPE_SMALL_CALL_KB"); return (size_t)(e ? atoi(e) : 2048) << 10; }();
+        const size_t span = (size_t)(noutput_items - 1) * nonoverlap + h->K;
+        const size_t span_al = (span + 1) & ~(size_t)1;
+        const size_t in_bytes = span_al * N * sizeof(float2);
+        if (in_bytes <= kSmallCallBytes) {
+            const size_t n = (size_t)noutput_items;
+            // sections of the result block [max | argmax | cov | spectrum], each on a 256-byte boundary (the scan kernels'
+            // 16-byte stores need aligned spectrum rows)
+            auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+            const size_t pk_b = n * M * sizeof(float);
+            const size_t cov_b = cov_out ? n * N * N * sizeof(float2) : 0, spec_b = spectrum_out ? n * P * sizeof(float) : 0;
+            const size_t off_am = up(pk_b), off_cov = off_am + up(pk_b), off_spec = off_cov + up(cov_b);
+            const size_t out_bytes = off_spec + spec_b;
+            const size_t res_min = (size_t)h->max_batch * M * 2 * sizeof(float);
+            int rc = h->h_stage.reserve(in_bytes > out_bytes ? in_bytes : out_bytes);
+            if (rc == DOA_OK) rc = h->d_in[0].reserve(in_bytes);
+            if (rc == DOA_OK) rc = h->d_res.reserve(out_bytes > res_min ? out_bytes : res_min);
+            if (rc != DOA_OK) return rc;
+            hipStream_t st = h->hst[0];
+            char *hs = h->h_stage.as<char>();
+            const void *d_ptrs[DOA_MAX_ANT_ELE];
+            for (int k = 0; k < N; k++) {
+                memcpy(hs + (size_t)k * span_al * sizeof(float2), input_items[k], span * sizeof(float2));
+                d_ptrs[k] = h->d_in[0].as<float2>() + (size_t)k * span_al;
+            }
+            DOA_HIP_TRY(hipMemcpyAsync(h->d_in[0].p, hs, in_bytes, hipMemcpyHostToDevice, st));
+            char *dr = h->d_res.as<char>();
+            float *d_mx = reinterpret_cast<float *>(dr), *d_am = reinterpret_cast<float *>(dr + off_am);
+            void *d_cov = cov_out ? (void *)(dr + off_cov) : h->d_cov.p;
+            void *d_spec = spectrum_out ? (void *)(dr + off_spec) : h->d_spec.p;
+            rc = run_dev(h, noutput_items, d_ptrs, d_cov, d_spec, d_mx, d_am, 0, st, 0);
+            if (rc < 0) return rc;
+            // (the staging buffer is free again: the upload was enqueued before the kernels on the same stream, and
+            // the download below is ordered behind them)
+            DOA_HIP_TRY(hipMemcpyAsync(hs, dr, out_bytes, hipMemcpyDeviceToHost, st));
+            DOA_HIP_TRY(hipStreamSynchronize(st));
+            memcpy(max_out, hs, pk_b);
+            memcpy(argmax_out, hs + off_am, pk_b);
+            if (cov_out) memcpy(cov_out, hs + off_cov, cov_b);
+            if (spectrum_out) memcpy(spectrum_out, hs + off_spec, spec_b);
+            return noutput_items;
+        }
+    }
     // Chunks of ~32 MiB of new samples alternate over two streams: while one chunk's results travel back
     // the next chunk's samples travel in (PCIe is full duplex; the kernels themselves are ~1 % of a
     // chunk's transfer time).  The overlap needs page-locked caller buffers; pageable ones still work.
-    const size_t nonoverlap = (size_t)(h->K - h->ovl);
     size_t chunk = ((size_t)32 << 20) / (nonoverlap * N * sizeof(float2));
     chunk = chunk < 1 ? 1 : (chunk > (size_t)noutput_items ? (size_t)noutput_items : chunk);
     const size_t span_max = (chunk - 1) * nonoverlap + h->K;

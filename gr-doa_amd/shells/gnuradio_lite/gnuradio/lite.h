@@ -8,6 +8,7 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <complex>
 #include <cstddef>
 #include <cstring>
@@ -39,6 +40,10 @@ public:
     {
         return sptr(new io_signature(min_streams, max_streams, std::vector<int>{size1, size2}));
     }
+    static sptr makev(int min_streams, int max_streams, const std::vector<int> &sizes)
+    {
+        return sptr(new io_signature(min_streams, max_streams, sizes));
+    }
     int min_streams() const { return d_min; }
     int max_streams() const { return d_max; }
     int sizeof_stream_item(int port) const
@@ -64,6 +69,10 @@ public:
     void set_history(unsigned h) { d_history = h; }
     void set_output_multiple(int m) { d_output_multiple = m; }
     int output_multiple() const { return d_output_multiple; }
+    // GNU Radio sizes a block's output buffers (and, through decimation x output_multiple, the buffers feeding it)
+    // from these; the scheduler then hands work() up to half a buffer per call
+    void set_min_output_buffer(long min_items) { d_min_output_buffer = min_items; }
+    long min_output_buffer() const { return d_min_output_buffer; }
     virtual bool fixed_rate() const { return false; }
     virtual void forecast(int noutput_items, gr_vector_int &ninput_items_required)
     {
@@ -82,6 +91,7 @@ protected:
     io_signature::sptr d_in, d_out;
     unsigned d_history = 1;
     int d_output_multiple = 1;
+    long d_min_output_buffer = -1;
     int d_consumed = 0;
 };
 
@@ -113,11 +123,17 @@ struct port_data {
 };
 
 // Feeds `inputs` (one buffer per input port, items of the block's input item size) through `blk`
-// with at most `max_noutput` items per call, honouring history/forecast/consume_each; returns one
-// buffer per output port.
+// with at most `max_noutput` items per call (what default-sized scheduler buffers would allow; a block that asked
+// for larger buffers gets calls of up to half of min_output_buffer()), in multiples of output_multiple() -- a
+// remainder smaller than one multiple is never processed, as in GNU Radio -- honouring
+// history/forecast/consume_each; returns one buffer per output port.  work_seconds (optional) accumulates the
+// wall time spent inside general_work().
 inline std::vector<port_data> run_block(block &blk, const std::vector<port_data> &inputs, int n_out_ports,
-                                        int max_noutput = 8)
+                                        int max_noutput = 8, double *work_seconds = nullptr)
 {
+    if (blk.min_output_buffer() > 0) max_noutput = std::max<long>(max_noutput, blk.min_output_buffer() / 2);
+    const int mult = std::max(1, blk.output_multiple());
+    max_noutput = std::max(mult, max_noutput - max_noutput % mult);
     const int n_in = (int)inputs.size();
     const unsigned hist = blk.history() - 1;
     std::vector<std::vector<char>> in(n_in);
@@ -131,10 +147,11 @@ inline std::vector<port_data> run_block(block &blk, const std::vector<port_data>
     std::vector<port_data> out(n_out_ports);
     for (int p = 0; p < n_out_ports; p++) out[p].item_size = (size_t)blk.output_signature()->sizeof_stream_item(p);
     size_t consumed = 0;
+    std::vector<std::vector<char>> ring_in(n_in), ring_out(n_out_ports);
     for (;;) {
         // largest noutput whose forecast fits into what is left
         int n = 0;
-        for (int cand = max_noutput; cand >= 1; cand--) {
+        for (int cand = max_noutput; cand >= mult; cand -= mult) {
             gr_vector_int req(n_in, 0);
             blk.forecast(cand, req);
             bool ok = true;
@@ -147,16 +164,31 @@ inline std::vector<port_data> run_block(block &blk, const std::vector<port_data>
         }
         if (n <= 0) break;
         gr_vector_int ninput(n_in, (int)(avail - consumed));
+        // GNU Radio's buffers are fixed rings: a block sees the SAME memory call after call (which is what lets the
+        // HIP runtime keep its pinning of a pageable buffer).  Model that: every call's input window is copied into a
+        // per-port scratch buffer that lives across calls (the upstream block's write, not this block's work), and the
+        // outputs are produced into persistent buffers and appended afterwards.
         gr_vector_const_void_star ip(n_in);
-        for (int p = 0; p < n_in; p++)
-            ip[p] = in[p].data() + consumed * (size_t)blk.input_signature()->sizeof_stream_item(p);
-        std::vector<std::vector<char>> ob(n_out_ports);
+        for (int p = 0; p < n_in; p++) {
+            const size_t isz = (size_t)blk.input_signature()->sizeof_stream_item(p);
+            gr_vector_int req(n_in, 0);
+            blk.forecast(n, req);
+            const size_t span = ((blk.fixed_rate() ? (size_t)n : (size_t)req[p]) + hist) * isz;
+            if (ring_in[p].size() < span) ring_in[p].resize(span);
+            std::memcpy(ring_in[p].data(), in[p].data() + consumed * isz, span);
+            ip[p] = ring_in[p].data();
+        }
         gr_vector_void_star op(n_out_ports);
-        for (int p = 0; p < n_out_ports; p++) { ob[p].resize((size_t)n * out[p].item_size); op[p] = ob[p].data(); }
+        for (int p = 0; p < n_out_ports; p++) {
+            if (ring_out[p].size() < (size_t)n * out[p].item_size) ring_out[p].resize((size_t)n * out[p].item_size);
+            op[p] = ring_out[p].data();
+        }
+        const auto t0 = std::chrono::steady_clock::now();
         const int produced = blk.general_work(n, ninput, ip, op);
+        if (work_seconds) *work_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (produced < 0) throw std::runtime_error(blk.name() + ": work() failed");
         for (int p = 0; p < n_out_ports; p++)
-            out[p].bytes.insert(out[p].bytes.end(), ob[p].begin(), ob[p].begin() + (size_t)produced * out[p].item_size);
+            out[p].bytes.insert(out[p].bytes.end(), ring_out[p].begin(), ring_out[p].begin() + (size_t)produced * out[p].item_size);
         if (blk.last_consumed() <= 0) break;
         consumed += (size_t)blk.last_consumed();
     }

@@ -9,6 +9,8 @@
 //                           (…/rootMUSIC_linear_array_impl.cc:46-49,96)
 //   antenna_correction      gr::sync_block, N complex streams in/out (…/antenna_correction_impl.cc:47-52)
 //   calibrate_lin_array     gr::sync_block, vlen N^2 complex -> vlen N complex (…/calibrate_lin_array_impl.cc:46-51)
+//   music_pipeline          (not in the reference) the first three wired as in run_MUSIC_lin_array_simulation.grc,
+//                           as one gr::block over doa_music_pipeline_work
 // — and turn a failing ABI call into the behaviour a GNU Radio block has for it: constructors throw
 // std::runtime_error / std::invalid_argument (as antenna_correction_impl.cc:58-73 does), work()
 // returns WORK_DONE (-1) after logging, which stops the flowgraph.
@@ -17,13 +19,16 @@
 #include <doa/autocorrelate.h>
 #include <doa/calibrate_lin_array.h>
 #include <doa/find_local_max.h>
+#include <doa/music_pipeline.h>
 #include <doa/rootMUSIC_linear_array.h>
 
 #include <doa_hip.h>
 
+#include <cstdlib>
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace gr {
 namespace doa {
@@ -38,6 +43,28 @@ int work_failed(const char *what, int status)
 {
     std::cerr << what << ": libdoa_hip status " << status << " (" << doa_last_error() << ")" << std::endl;
     return gr::block::WORK_DONE;
+}
+
+// Flowgraph-rate plumbing.  Under GNU Radio's default 64 KiB buffers these blocks see calls of a
+// handful of items, and a call costs 50-100 us of launches, copies and one stream synchronisation whatever its
+// size.  Two scheduler knobs change that, both set here from the environment so that a flowgraph needs no edit:
+//   DOA_GR_MIN_OUTPUT_BUFFER  items the block's output buffers must hold (default 2048; 0 = GNU Radio's default):
+//                             the scheduler then hands over up to half of that whenever upstream has it ready --
+//                             larger calls, no added latency, no change at end of stream;
+//   DOA_GR_OUTPUT_MULTIPLE    work() is only called with a multiple of this many items (default 1 = the reference's
+//                             scheduling).  For gr::block's with a decimation (autocorrelate, music_pipeline) GNU
+//                             Radio also sizes the INPUT buffers from it (2 x multiple x (snapshot - overlap) samples),
+//                             which is what lets a radio-rate flowgraph reach the PCIe-bound rate; the price is
+//                             GNU Radio's own: up to multiple - 1 trailing items are not processed when a finite
+//                             source ends.
+void apply_scheduling_hints(gr::block *b)
+{
+    const char *e = getenv("DOA_GR_MIN_OUTPUT_BUFFER");
+    const long min_buf = e ? atol(e) : 2048;
+    if (min_buf > 0) b->set_min_output_buffer(min_buf);
+    e = getenv("DOA_GR_OUTPUT_MULTIPLE");
+    const int mult = e ? atoi(e) : 1;
+    if (mult > 1) b->set_output_multiple(mult);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -55,6 +82,7 @@ public:
     {
         if (!d_h) throw_create("doa::autocorrelate");
         set_history(doa_autocorrelate_history(d_h));          // overlap_size + 1
+        apply_scheduling_hints(this);
     }
     ~autocorrelate_hip() override { doa_autocorrelate_destroy(d_h); }
 
@@ -86,6 +114,7 @@ public:
           d_h(doa_MUSIC_lin_array_create(norm_spacing, num_targets, num_ant_ele, pspectrum_len))
     {
         if (!d_h) throw_create("doa::MUSIC_lin_array");
+        apply_scheduling_hints(this);
     }
     ~MUSIC_lin_array_hip() override
     {
@@ -112,6 +141,7 @@ public:
           d_h(doa_find_local_max_create(num_max_vals, vector_len, x_min, x_max))
     {
         if (!d_h) throw_create("doa::find_local_max");
+        apply_scheduling_hints(this);
     }
     ~find_local_max_hip() override { doa_find_local_max_destroy(d_h); }
     int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) override
@@ -134,6 +164,7 @@ public:
           d_h(doa_rootMUSIC_linear_array_create(norm_spacing, num_targets, num_ant_ele))
     {
         if (!d_h) throw_create("doa::rootMUSIC_linear_array");
+        apply_scheduling_hints(this);
     }
     ~rootMUSIC_linear_array_hip() override { doa_rootMUSIC_linear_array_destroy(d_h); }
     int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) override
@@ -177,6 +208,7 @@ public:
           d_h(doa_calibrate_lin_array_create(norm_spacing, num_ant_ele, pilot_angle))
     {
         if (!d_h) throw_create("doa::calibrate_lin_array");
+        apply_scheduling_hints(this);
     }
     ~calibrate_lin_array_hip() override { doa_calibrate_lin_array_destroy(d_h); }
     int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) override
@@ -186,8 +218,73 @@ public:
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// autocorrelate -> MUSIC_lin_array -> find_local_max as one block over doa_music_pipeline_work: one upload, the
+// whole chain on the device, one download of the connected ports (see include/doa/music_pipeline.h)
+class music_pipeline_hip : public music_pipeline
+{
+    static constexpr int kMaxBatch = 4096;
+    doa_music_pipeline_t *d_h;
+    int d_nonoverlap, d_M, d_P;
+    std::vector<float> d_max_scratch;                     // port 1 (peak values) when it is not connected
+
+public:
+    music_pipeline_hip(int inputs, int snapshot_size, int overlap_size, int avg_method, float norm_spacing,
+                       int num_targets, int pspectrum_len)
+        : gr::block("music_pipeline", gr::io_signature::make(inputs, inputs, sizeof(gr_complex)),
+                    gr::io_signature::makev(1, 3, std::vector<int>{(int)(num_targets * sizeof(float)),
+                                                                   (int)(num_targets * sizeof(float)),
+                                                                   (int)(pspectrum_len * sizeof(float))})),
+          d_h(doa_music_pipeline_create(inputs, snapshot_size, overlap_size, avg_method, norm_spacing, num_targets,
+                                        pspectrum_len, kMaxBatch)),
+          d_nonoverlap(snapshot_size - overlap_size), d_M(num_targets), d_P(pspectrum_len)
+    {
+        if (!d_h) throw_create("doa::music_pipeline");
+        set_history(overlap_size + 1);                        // as doa::autocorrelate (autocorrelate_impl.cc:56-57)
+        apply_scheduling_hints(this);
+    }
+    ~music_pipeline_hip() override { doa_music_pipeline_destroy(d_h); }
+
+    void forecast(int noutput_items, gr_vector_int &ninput_items_required) override
+    {
+        for (auto &n : ninput_items_required) n = d_nonoverlap * noutput_items;     // autocorrelate_impl.cc:75-80
+    }
+
+    int general_work(int noutput_items, gr_vector_int &, gr_vector_const_void_star &input_items,
+                     gr_vector_void_star &output_items) override
+    {
+        float *argmax = static_cast<float *>(output_items[0]);
+        float *maxv = output_items.size() > 1 ? static_cast<float *>(output_items[1]) : nullptr;
+        float *spec = output_items.size() > 2 ? static_cast<float *>(output_items[2]) : nullptr;
+        if (!maxv) {
+            d_max_scratch.resize((size_t)kMaxBatch * d_M);
+            maxv = d_max_scratch.data();
+        }
+        std::vector<const void *> in(input_items.size());
+        int done = 0;
+        while (done < noutput_items) {                        // the handle's workspace holds kMaxBatch items
+            const int n = noutput_items - done < kMaxBatch ? noutput_items - done : kMaxBatch;
+            for (size_t k = 0; k < in.size(); k++)
+                in[k] = static_cast<const gr_complex *>(input_items[k]) + (size_t)done * d_nonoverlap;
+            float *mv = output_items.size() > 1 ? maxv + (size_t)done * d_M : maxv;
+            const int produced = doa_music_pipeline_work(d_h, n, in.data(), nullptr, spec ? spec + (size_t)done * d_P : nullptr,
+                                                         mv, argmax + (size_t)done * d_M);
+            if (produced < 0) return work_failed("doa::music_pipeline", produced);
+            done += produced;
+        }
+        consume_each(d_nonoverlap * done);                    // autocorrelate_impl.cc:114
+        return done;
+    }
+};
+
 }  // namespace
 
+music_pipeline::sptr music_pipeline::make(int inputs, int snapshot_size, int overlap_size, int avg_method,
+                                          float norm_spacing, int num_targets, int pspectrum_len)
+{
+    return gnuradio::get_initial_sptr(new music_pipeline_hip(inputs, snapshot_size, overlap_size, avg_method, norm_spacing,
+                                                             num_targets, pspectrum_len));
+}
 calibrate_lin_array::sptr calibrate_lin_array::make(float norm_spacing, int num_ant_ele, float pilot_angle)
 {
     return gnuradio::get_initial_sptr(new calibrate_lin_array_hip(norm_spacing, num_ant_ele, pilot_angle));

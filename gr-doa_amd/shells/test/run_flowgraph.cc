@@ -2,6 +2,7 @@
 // (apps/run_MUSIC_lin_array_simulation.grc, apps/run_RootMUSIC_lin_array_simulation.grc):
 //     N stream files -> autocorrelate -> MUSIC_lin_array -> find_local_max   (mode "music")
 //     N stream files -> autocorrelate -> rootMUSIC_linear_array               (mode "root")
+//     N stream files -> music_pipeline (the three blocks of "music" as one)   (mode "pipeline")
 // Inputs/outputs are raw little-endian binary files so that the pytest driver (tests/
 // test_gpu_shells.py) can compare every port with the Python binding and the oracle.
 //
@@ -10,9 +11,12 @@
 //   reads  <in_prefix>.ch<k>.c64   (gr_complex samples of stream k, no history)
 //   writes <out_prefix>.cov.c64, .spec.f32, .max.f32, .argmax.f32   (music)
 //          <out_prefix>.cov.c64, .aoa.f32                            (root)
+//          <out_prefix>.spec.f32, .max.f32, .argmax.f32              (pipeline)
+// and prints the wall time spent inside the blocks' work() calls (host buffers in, host buffers out).
 #include <doa/MUSIC_lin_array.h>
 #include <doa/autocorrelate.h>
 #include <doa/find_local_max.h>
+#include <doa/music_pipeline.h>
 #include <doa/rootMUSIC_linear_array.h>
 
 #include <cstdio>
@@ -41,7 +45,7 @@ static void write_file(const std::string &path, const port_data &d)
 int main(int argc, char **argv)
 {
     if (argc != 12) {
-        std::cerr << "usage: run_flowgraph music|root in_prefix out_prefix inputs snapshot overlap avg norm_spacing "
+        std::cerr << "usage: run_flowgraph music|root|pipeline in_prefix out_prefix inputs snapshot overlap avg norm_spacing "
                      "num_targets pspectrum_len max_noutput\n";
         return 2;
     }
@@ -53,19 +57,40 @@ int main(int argc, char **argv)
         std::vector<port_data> streams;
         for (int k = 0; k < inputs; k++) streams.push_back(read_file(in_prefix + ".ch" + std::to_string(k) + ".c64", sizeof(gr_complex)));
 
+        double work_s = 0.0;
+        if (mode == "pipeline") {
+            auto pipe = gr::doa::music_pipeline::make(inputs, snapshot, overlap, avg, d, M, P);
+            auto out = gr::lite::run_block(*pipe, streams, 3, max_noutput);      // first pass: code load, buffer allocation
+            write_file(out_prefix + ".argmax.f32", out[0]);
+            write_file(out_prefix + ".max.f32", out[1]);
+            write_file(out_prefix + ".spec.f32", out[2]);
+            auto again = gr::lite::run_block(*pipe, streams, 3, max_noutput, &work_s);   // timed: the same stream once more
+            if (again[0].bytes != out[0].bytes || again[2].bytes != out[2].bytes) throw std::runtime_error("music_pipeline: second pass differs");
+            std::cout << "items: peaks " << out[0].items() << " spec " << out[2].items() << "\nwork_seconds " << work_s
+                      << " snapshots_per_s " << (work_s > 0 ? out[0].items() / work_s : 0.0) << std::endl;
+            // the same block with only port 0 connected (angles out: nothing else crosses PCIe on the way back)
+            auto pipe1 = gr::doa::music_pipeline::make(inputs, snapshot, overlap, avg, d, M, P);
+            double w1 = 0.0;
+            auto out1 = gr::lite::run_block(*pipe1, streams, 1, max_noutput);
+            out1 = gr::lite::run_block(*pipe1, streams, 1, max_noutput, &w1);
+            if (out1[0].bytes != out[0].bytes) throw std::runtime_error("music_pipeline: port 0 differs with ports 1, 2 unconnected");
+            std::cout << "angles_only work_seconds " << w1 << " snapshots_per_s " << (w1 > 0 ? out1[0].items() / w1 : 0.0) << std::endl;
+            return 0;
+        }
         auto ac = gr::doa::autocorrelate::make(inputs, snapshot, overlap, avg);
-        auto cov = gr::lite::run_block(*ac, streams, 1, max_noutput);
+        auto cov = gr::lite::run_block(*ac, streams, 1, max_noutput, &work_s);
         write_file(out_prefix + ".cov.c64", cov[0]);
 
         if (mode == "music") {
             auto music = gr::doa::MUSIC_lin_array::make(d, M, inputs, P);
-            auto spec = gr::lite::run_block(*music, {cov[0]}, 1, max_noutput);
+            auto spec = gr::lite::run_block(*music, {cov[0]}, 1, max_noutput, &work_s);
             write_file(out_prefix + ".spec.f32", spec[0]);
             auto fmax = gr::doa::find_local_max::make(M, P, 0.0f, 180.0f);
-            auto pk = gr::lite::run_block(*fmax, {spec[0]}, 2, max_noutput);
+            auto pk = gr::lite::run_block(*fmax, {spec[0]}, 2, max_noutput, &work_s);
             write_file(out_prefix + ".max.f32", pk[0]);
             write_file(out_prefix + ".argmax.f32", pk[1]);
-            std::cout << "items: cov " << cov[0].items() << " spec " << spec[0].items() << " peaks " << pk[0].items() << std::endl;
+            std::cout << "items: cov " << cov[0].items() << " spec " << spec[0].items() << " peaks " << pk[0].items()
+                      << "\nwork_seconds " << work_s << " snapshots_per_s " << (work_s > 0 ? pk[0].items() / work_s : 0.0) << std::endl;
         } else {
             auto root = gr::doa::rootMUSIC_linear_array::make(d, M, inputs);
             auto aoa = gr::lite::run_block(*root, {cov[0]}, 1, max_noutput);

@@ -18,26 +18,33 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "gr-doa_amd", "lib", "run_flowgraph")
 
 
-def _run(mode, c, x_new, tmp_path, max_noutput):
+def _run(mode, c, x_new, tmp_path, max_noutput, env=None, tag="out"):
+    """max_noutput = the call size GNU Radio's default buffers would allow.  The shells ask for larger output
+    buffers (DOA_GR_MIN_OUTPUT_BUFFER, default 2048 items -> calls of up to 1024); SMALL_CALLS switches that off so
+    that scheduler-sized calls of a few items stay covered."""
     pre = str(tmp_path / "in")
-    out = str(tmp_path / "out")
+    out = str(tmp_path / tag)
     for k in range(c["N"]):
         x_new[k].astype(np.complex64).tofile(f"{pre}.ch{k}.c64")
     cmd = [EXE, mode, pre, out, str(c["N"]), str(c["K"]), str(c["ovl"]), str(c["fb"]), repr(float(np.float32(c["d"]))),
            str(c["M"]), str(c["P"]), str(max_noutput)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr + r.stdout
     return out, r.stdout
 
 
-@pytest.mark.parametrize("name,max_noutput", [("grc_music_sim", 3), ("bench_cfg2", 8), ("three_ant_fb", 1)])
-def test_music_flowgraph_through_cpp_shells(tmp_path, name, max_noutput):
+SMALL_CALLS = {"DOA_GR_MIN_OUTPUT_BUFFER": "0"}
+
+
+@pytest.mark.parametrize("name,max_noutput,env", [("grc_music_sim", 3, SMALL_CALLS), ("bench_cfg2", 8, SMALL_CALLS),
+                                                  ("three_ant_fb", 1, SMALL_CALLS), ("grc_music_sim", 3, None)])
+def test_music_flowgraph_through_cpp_shells(tmp_path, name, max_noutput, env):
     assert os.path.exists(EXE), "build the shells: make -C gr-doa_amd/shells"
     c, x = make_input(name)
     N, M, P = c["N"], c["M"], c["P"]
     S = c["K"] - c["ovl"]
     x_new = x[:, : (x.shape[1] // S) * S]                       # what the sources emit (no history)
-    out, log = _run("music", c, x_new, tmp_path, max_noutput)
+    out, log = _run("music", c, x_new, tmp_path, max_noutput, env)
     cov = np.fromfile(out + ".cov.c64", np.complex64).reshape(-1, N * N)
     spec = np.fromfile(out + ".spec.f32", np.float32).reshape(-1, P)
     mx = np.fromfile(out + ".max.f32", np.float32).reshape(-1, M)
@@ -64,6 +71,29 @@ def test_music_flowgraph_through_cpp_shells(tmp_path, name, max_noutput):
     assert np.abs(cov - R64).max() <= 2e-6 * np.abs(R64).max()
     _, _, _, loc = oracle.music_pipeline(xh, c["K"], c["ovl"], c["fb"], c["d"], M, P, n)
     assert np.abs(am - loc).max() <= 180.0 / P + 1e-3
+
+
+@pytest.mark.parametrize("name,env", [("grc_music_sim", None), ("grc_music_sim", SMALL_CALLS), ("bench_cfg2", SMALL_CALLS),
+                                      ("grc_music_sim", {"DOA_GR_OUTPUT_MULTIPLE": "4"})])
+def test_pipeline_shell_equals_the_three_chained_shells(tmp_path, name, env):
+    """gr::doa::music_pipeline (one block over doa_music_pipeline_work) against autocorrelate -> MUSIC_lin_array ->
+    find_local_max wired as apps/run_MUSIC_lin_array_simulation.grc does: every port bit for bit, whatever the
+    call size; with an output multiple the trailing remainder is not produced (GNU Radio's rule)."""
+    c, x = make_input(name)
+    M, P = c["M"], c["P"]
+    S = c["K"] - c["ovl"]
+    x_new = x[:, : (x.shape[1] // S) * S]
+    chain, _ = _run("music", c, x_new, tmp_path, 3, SMALL_CALLS, tag="chain")
+    pipe, log = _run("pipeline", c, x_new, tmp_path, 5, env, tag="pipe")
+    n_all = x_new.shape[1] // S
+    mult = int((env or {}).get("DOA_GR_OUTPUT_MULTIPLE", "1"))
+    n = (n_all // mult) * mult
+    for port, width in (("argmax.f32", M), ("max.f32", M), ("spec.f32", P)):
+        a = np.fromfile(f"{chain}.{port}", np.float32).reshape(-1, width)
+        b = np.fromfile(f"{pipe}.{port}", np.float32).reshape(-1, width)
+        assert a.shape[0] == n_all and b.shape[0] == n, (port, a.shape, b.shape)
+        assert np.array_equal(a[:n], b), port
+    assert "angles_only" in log                                   # ports 1, 2 unconnected: port 0 unchanged (checked there)
 
 
 def test_root_music_flowgraph_through_cpp_shells(tmp_path):

@@ -138,9 +138,9 @@ if "host" in args.stages:
             hx = [t.pin_memory() for t in hx]; h_mx, h_am, h_spec = h_mx.pin_memory(), h_am.pin_memory(), h_spec.pin_memory()
         xs = [t.numpy() for t in hx]
         for what, sp in (("angles", None), ("spectrum", h_spec.numpy())):
-            for nit in (B, 8):
+            for nit in (B, 1024, 256, 64, 8):
                 pipe.work(nit, xs, h_mx.numpy(), h_am.numpy(), spectrum_out=sp)
-                reps = 5 if nit == B else 200
+                reps = 5 if nit == B else (20 if nit >= 1024 else 200)
                 t0 = time.perf_counter()
                 for _ in range(reps):
                     pipe.work(nit, xs, h_mx.numpy(), h_am.numpy(), spectrum_out=sp)
