@@ -303,7 +303,7 @@ class music_pipeline(_Block):
     _destroy = staticmethod(lib.doa_music_pipeline_destroy)
 
     def __init__(self, inputs, snapshot_size, overlap_size, avg_method, norm_spacing, num_targets,
-                 pspectrum_len, max_batch):
+                 pspectrum_len, max_batch=4096):
         super().__init__()
         self.inputs, self.snapshot_size, self.overlap_size = int(inputs), int(snapshot_size), int(overlap_size)
         self.avg_method, self.norm_spacing = int(avg_method), float(norm_spacing)
@@ -311,6 +311,29 @@ class music_pipeline(_Block):
         self._h = check_handle(lib.doa_music_pipeline_create(self.inputs, self.snapshot_size, self.overlap_size,
                                                              self.avg_method, self.norm_spacing, self.num_targets,
                                                              self.pspectrum_len, self.max_batch), "music_pipeline")
+        # as a flowgraph block (gr::doa::music_pipeline of the C++ shells, grc/doa_music_pipeline.xml): N complex
+        # streams in; out0 = peak locations, out1 = peak values, out2 = spectrum
+        self.in_sig = [(_C64, 1)] * self.inputs
+        self.out_sig = [(_F32, self.num_targets), (_F32, self.num_targets), (_F32, self.pspectrum_len)]
+
+    def history(self) -> int:
+        return self.overlap_size + 1                          # as doa.autocorrelate (autocorrelate_impl.cc:56-57)
+
+    def forecast(self, noutput_items: int) -> int:
+        return (self.snapshot_size - self.overlap_size) * int(noutput_items)
+
+    def general_work(self, noutput_items, input_items, output_items):
+        """output_items = [argmax [>=n, M], max [>=n, M], spectrum [>=n, P]] (trailing ports may be omitted).
+        Returns (items produced, items consumed per input)."""
+        n, done = int(noutput_items), 0
+        S = self.snapshot_size - self.overlap_size
+        while done < n:
+            k = min(self.max_batch, n - done)
+            am = output_items[0][done:done + k]
+            mx = output_items[1][done:done + k] if len(output_items) > 1 else np.empty((k, self.num_targets), _F32)
+            sp = output_items[2][done:done + k] if len(output_items) > 2 else None
+            done += self.work(k, [a[done * S:] for a in input_items], mx, am, spectrum_out=sp)
+        return done, self.forecast(done)
 
     def fuse_antenna_correction(self, correction) -> None:
         _fuse(lib.doa_music_pipeline_fuse_antenna_correction, self._h, correction, self.inputs)

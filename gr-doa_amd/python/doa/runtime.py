@@ -109,20 +109,18 @@ class top_block:
             in_arrays = [a.reshape(-1) for a in in_arrays]           # stream ports carry scalar items
             streams = [np.concatenate([np.zeros(hist, dtype=a.dtype), a]) for a in in_arrays]
             n_new = min(a.shape[0] for a in in_arrays)
-            vlen = b.out_sig[0][1]
-            chunks, consumed = [], 0
+            chunks, consumed = [[] for _ in b.out_sig], 0
             while True:
                 avail_new = n_new - consumed
                 n = min(mno, avail_new // b.forecast(1))
                 if n <= 0:
                     break
-                out = np.empty((n, vlen), dtype=b.out_sig[0][0])
-                produced, used = b.general_work(n, [s[consumed:] for s in streams], [out])
-                chunks.append(out[:produced])
+                outs = [np.empty((n, vl), dtype=dt) for dt, vl in b.out_sig]
+                produced, used = b.general_work(n, [s[consumed:] for s in streams], outs)
+                for c, o in zip(chunks, outs):
+                    c.append(o[:produced])
                 consumed += used                      # consume_each
-            if not chunks:
-                return [np.zeros((0, vlen), dtype=b.out_sig[0][0])]
-            return [np.concatenate(chunks)]
+            return [np.concatenate(c) if c else np.zeros((0, vl), dtype=dt) for c, (dt, vl) in zip(chunks, b.out_sig)]
         # gr::sync_block (one or several input ports, all at the same rate)
         ins = []
         for a, (dt, vl) in zip(in_arrays, b.in_sig):

@@ -35,6 +35,13 @@ EXPECT = {
         params={"norm_spacing": "0.5", "num_ant_ele": "4", "pilot_angle": "45.0"},
         checks=["$num_ant_ele > 1", "$norm_spacing <= 0.5"],
         sinks=[("complex", "$num_ant_ele*$num_ant_ele", None)], sources=[("complex", "$num_ant_ele", None)]),
+    "doa_music_pipeline": dict(          # not a reference block: the three blocks above as one, same parameter keys
+        make="doa.music_pipeline($inputs, $snapshot_size, $overlap_size, $avg_method, $norm_spacing, $num_targets, $pspectrum_len)",
+        params={"inputs": "4", "snapshot_size": "2048", "overlap_size": "512", "avg_method": "0", "norm_spacing": "0.5",
+                "num_targets": "1", "pspectrum_len": "1024"},
+        checks=["$inputs > 0", "$inputs > $num_targets", "$norm_spacing <= 0.5", "$overlap_size < $snapshot_size"],
+        sinks=[("complex", None, "$inputs")],
+        sources=[("float", "$num_targets", None), ("float", "$num_targets", None), ("float", "$pspectrum_len", None)]),
     "doa_rootMUSIC_linear_array": dict(
         make="doa.rootMUSIC_linear_array($norm_spacing, $num_targets, $inputs)",
         params={"norm_spacing": "0.5", "num_targets": "1", "inputs": "1"},

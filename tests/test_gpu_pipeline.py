@@ -144,3 +144,42 @@ def test_pipeline_host_entry_multi_chunk(K, ovl, fb, M):
     torch.cuda.synchronize()
     assert np.array_equal(h_spec, spec.cpu().numpy())
     assert np.array_equal(h_mx, mx.cpu().numpy()) and np.array_equal(h_am, am.cpu().numpy())
+
+
+def test_pipeline_as_one_flowgraph_block_equals_the_three_block_chain():
+    """doa.music_pipeline wired as a block (grc/doa_music_pipeline.xml: N streams in, locations / values / spectrum
+    out) against autocorrelate -> MUSIC_lin_array -> find_local_max in the same mini flowgraph runtime, with
+    scheduler-sized calls: every port bit for bit (history pre-roll, forecast and consume_each included)."""
+    c, x = make_input("grc_music_sim")
+    N, M, P, K, ovl = c["N"], c["M"], c["P"], c["K"], c["ovl"]
+    S = K - ovl
+    x_new = x[:, : (x.shape[1] // S) * S]
+
+    def run(chain):
+        tb = doa.runtime.top_block(max_noutput_items=5)
+        srcs = [doa.runtime.vector_source_c(x_new[k]) for k in range(N)]
+        sinks = [doa.runtime.vector_sink_f(M), doa.runtime.vector_sink_f(M), doa.runtime.vector_sink_f(P)]
+        if chain:
+            a = doa.autocorrelate(N, K, ovl, c["fb"])
+            m = doa.MUSIC_lin_array(c["d"], M, N, P)
+            f = doa.find_local_max(M, P, 0.0, 180.0)
+            for k in range(N):
+                tb.connect((srcs[k], 0), (a, k))
+            tb.connect((a, 0), (m, 0))
+            tb.connect((m, 0), (f, 0))
+            tb.connect((f, 1), (sinks[0], 0))
+            tb.connect((f, 0), (sinks[1], 0))
+            tb.connect((m, 0), (sinks[2], 0))
+        else:
+            p = doa.music_pipeline(N, K, ovl, c["fb"], c["d"], M, P)         # the GRC make string's seven arguments
+            for k in range(N):
+                tb.connect((srcs[k], 0), (p, k))
+            for port in range(3):
+                tb.connect((p, port), (sinks[port], 0))
+        tb.run()
+        return [s.data() for s in sinks]
+
+    one, three = run(False), run(True)
+    assert one[0].shape[0] == (x_new.shape[1] // S) * M
+    for a, b in zip(one, three):
+        assert np.array_equal(a, b)
