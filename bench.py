@@ -14,11 +14,12 @@ covariance (K1), Hermitian EVD + noise projector (K2+K3), spectrum scan (K4), pe
 distinct input/output batches whose total footprint exceeds the 256 MiB Infinity Cache, so every
 step streams from HBM (a single 144 MiB working set would be served on-die).
 
-Steps alternate over a few HIP streams (default 3, one pipeline handle = one workspace per
+Steps alternate over a few HIP streams (default 4, one pipeline handle = one workspace per
 stream): each step's three launches stay in order on its own stream, while the HBM-bound covariance
 of one batch overlaps the latency-bound EVD / scan of the batches before it (the covariance kernel fills
 the register file of every SIMD, so the EVD / scan of step i really run beside the covariance of step
-i + 2: three streams are what keeps that from stalling the covariance of step i + 2).
+i + 2: three or four streams keep that from stalling the covariance of step i + 2; same-box A/B runs put four ahead
+of three by 1-3 us per step more often than not).
 
 Multi-GPU (weak scaling): snapshots are independent, so every rank owns its own batch and there is
 no data-path collective; value = (steps * batch * world) / max-over-ranks time.  After the timed region the
@@ -317,7 +318,7 @@ def main():
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
                     help="internal precision of EVD + scan (items are fp32 either way)")
     ap.add_argument("--nbuf", type=int, default=6, help="distinct batches rotated through (defeats L3 residency)")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams the steps alternate over")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the steps alternate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scan-roofline", action="store_true",
                     help="skip the isolated scan-kernel measurements (keeps rocprof kernel averages clean)")

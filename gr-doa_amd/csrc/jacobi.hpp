@@ -50,7 +50,8 @@ template <> struct Real<double> {
 // the parameter chain is what a batched small-matrix Jacobi waits on.
 // Matrices are pre-scaled to max |entry| in [1, 2) (jacobi_prescale), so the float intermediates cannot
 // overflow and a pivot with |a_pq|^2 < 1e-30 is zero at any working precision.
-template <typename T> struct JacobiRot { T c, sr, si, rho; };     // rho: (J^H A J)[p][q] = rho a_pq, the pivot's residue
+// rho: (J^H A J)[p][q] = rho a_pq, the pivot's residue; ss = |sigma|^2; csg = 2 c Re(conj(sigma) a_pq)
+template <typename T> struct JacobiRot { T c, sr, si, rho, ss, csg; };
 template <typename T>
 __device__ __forceinline__ JacobiRot<T> jacobi_rotation(T app, T aqq, T xr, T xi, bool enable = true)
 {
@@ -68,7 +69,33 @@ __device__ __forceinline__ JacobiRot<T> jacobi_rotation(T app, T aqq, T xr, T xi
     const T ck = y * kappa;
     // (J^H A J)[p][q] = c^2 a_pq (1 - 2 kappa d - kappa^2 |a_pq|^2): zero for the exact kappa, ~1e-7 for the float one
     const T rho = (y * y) * fma((T)-2 * kappa, d, (T)2 - x);
-    return {y, ck * xr, ck * xi, rho};
+    const T sr = ck * xr, si = ck * xi;
+    return {y, sr, si, rho, fma(sr, sr, si * si), (T)2 * y * fma(sr, xr, si * xi)};
+}
+
+// The classical parameters, everything in T: c, s and e^{j phi} from rsqrt only (three dependent T-precision rsqrt),
+// the pivot annihilated to working precision (rho = 0).  Slower on its own than jacobi_rotation (10.4 against 9.6 us
+// per 4096 4 x 4 items, one lane per item), but the one-lane-per-item kernel built on it costs the 4-stream pipeline
+// 1-2 us LESS per step (same-box A/B, three repetitions: 26.1-26.3 against 26.9-28.1 us): that kernel shares its SIMDs
+// with the covariance kernel of the next batch, and what counts there is how its instruction stream interleaves, not
+// its length.  So the lane-per-item kernel uses this one; the lanes-per-item kernels (N > 4) use jacobi_rotation.
+template <typename T>
+__device__ __forceinline__ JacobiRot<T> jacobi_rotation_classic(T app, T aqq, T xr, T xi)
+{
+    const T g2 = xr * xr + xi * xi;
+    const bool live = g2 > Real<T>::tiny;                        // a pivot that is already zero gets the identity
+    const T inv_g = Real<T>::rsqrt(live ? g2 : (T)1);
+    const T phr = xr * inv_g, phi = xi * inv_g;                   // e^{j phi}
+    T tau = (aqq - app) * (T)0.5 * inv_g;
+    tau = fmin(fmax(tau, -Real<T>::tau_max), Real<T>::tau_max);
+    const T x1 = fma(tau, tau, (T)1);
+    const T r = x1 * Real<T>::rsqrt(x1);                          // sqrt(1 + tau^2)
+    const T h = fabs(tau) + r;                                    // 1/|t|
+    const T w = Real<T>::rsqrt(fma(h, h, (T)1));
+    const T g = live ? g2 * inv_g : (T)0;
+    const T c = live ? h * w : (T)1;
+    const T sn = live ? copysign(w, tau) : (T)0;
+    return {c, sn * phr, sn * phi, (T)0, sn * sn, (T)2 * c * sn * g};
 }
 
 // Exact power-of-two scale that brings max |entry| into [1, 2) (eigenvectors, ranks and therefore P_N do not
@@ -88,7 +115,7 @@ template <typename T> __device__ __forceinline__ T jacobi_prescale(float m)
 // tau = (A[q][q]-A[p][p]) / (2|A[p][q]|).  c, s and e^{j phi} are built from rsqrt only, so J is
 // unitary to working precision and no division appears.  A <- J^H A J touches, for every k not in
 // {p,q}, the pair (A[k][p], A[k][q]) and the two diagonal entries; V <- V J touches columns p, q.
-template <int N, typename T, bool UNROLL>
+template <int N, typename T, bool UNROLL, bool CLASSIC = false>
 __device__ __forceinline__ void herm_jacobi(T (&dg)[N], T (&ur)[N][N], T (&ui)[N][N], T (&vr)[N][N], T (&vi)[N][N])
 {
     constexpr int U = UNROLL ? N : 1;
@@ -109,16 +136,18 @@ __device__ __forceinline__ void herm_jacobi(T (&dg)[N], T (&ur)[N][N], T (&ui)[N
             for (int q = 1; q < N; q++) {
                 if (q <= p) continue;
                 const T apr = ur[p][q], api = ui[p][q];
-                const JacobiRot<T> rot = jacobi_rotation<T>(dg[p], dg[q], apr, api);
+                const JacobiRot<T> rot = CLASSIC ? jacobi_rotation_classic<T>(dg[p], dg[q], apr, api)
+                                                 : jacobi_rotation<T>(dg[p], dg[q], apr, api);
                 const T c = rot.c, spr = rot.sr, spi = rot.si;         // sigma
                 // 2x2 block: a_pp' = c^2 a_pp - 2c Re(conj(sigma) a_pq) + |sigma|^2 a_qq,  a_qq' = |sigma|^2 a_pp + 2c Re(..) + c^2 a_qq,
                 // a_pq' = rho a_pq: what J^H A J really leaves there (the float angle does not annihilate it exactly)
                 {
-                    const T cc = c * c, ss = fma(spr, spr, spi * spi), csg = (T)2 * c * fma(spr, apr, spi * api);
+                    const T cc = c * c, ss = rot.ss, csg = rot.csg;
                     const T app = dg[p], aqq = dg[q];
                     dg[p] = fma(cc, app, fma(ss, aqq, -csg));
                     dg[q] = fma(ss, app, fma(cc, aqq, csg));
-                    ur[p][q] = rot.rho * apr; ui[p][q] = rot.rho * api;
+                    if constexpr (CLASSIC) { ur[p][q] = 0; ui[p][q] = 0; }
+                    else { ur[p][q] = rot.rho * apr; ui[p][q] = rot.rho * api; }
                 }
                 // off-diagonal pairs (A[k][p], A[k][q]), k not in {p,q}:
                 //   x' = c x - conj(sigma) y,   y' = sigma x + c y
@@ -176,31 +205,18 @@ __device__ __forceinline__ void evd_item_coefficients(const float2 *__restrict__
     for (int r = 0; r < N; r++)
 #pragma unroll U
         for (int c = 0; c < N; c++) { vr[r][c] = (r == c) ? (T)1 : (T)0; vi[r][c] = 0; }
-    T poison = 0;            // 0, or NaN when the item holds a non-finite entry (0 * inf = 0 * NaN = NaN)
-    {
-        float m = 0.f;
+    // 0, or NaN when the item holds a non-finite entry (0 * inf = 0 * NaN = NaN).  (No pre-scaling here: the classical
+    // rotation works in T throughout, and float-origin data cannot leave double's range.)
+    T poison = 0;
 #pragma unroll U
-        for (int c = 0; c < N; c++) {
-            m = fmaxf(m, fabsf((float)dg[c]));
-            poison = fma(dg[c], (T)0, poison);
+    for (int c = 0; c < N; c++) {
+        poison = fma(dg[c], (T)0, poison);
 #pragma unroll U
-            for (int r = 0; r < N; r++)
-                if (r < c) {
-                    m = fmaxf(m, fmaxf(fabsf((float)ar[r][c]), fabsf((float)ai[r][c])));
-                    poison = fma(ar[r][c], (T)0, fma(ai[r][c], (T)0, poison));
-                }
-        }
-        const T sc = jacobi_prescale<T>(m);
-#pragma unroll U
-        for (int c = 0; c < N; c++) {
-            dg[c] *= sc;
-#pragma unroll U
-            for (int r = 0; r < N; r++)
-                if (r < c) { ar[r][c] *= sc; ai[r][c] *= sc; }
-        }
+        for (int r = 0; r < N; r++)
+            if (r < c) poison = fma(ar[r][c], (T)0, fma(ai[r][c], (T)0, poison));
     }
 
-    herm_jacobi<N, T, UNROLL>(dg, ar, ai, vr, vi);
+    herm_jacobi<N, T, UNROLL, true>(dg, ar, ai, vr, vi);
 
     // ascending rank of each eigenvalue (eig_sym contract); noise set = ranks < N-M
     T sel[N];

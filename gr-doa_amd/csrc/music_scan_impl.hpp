@@ -52,33 +52,40 @@ __device__ __forceinline__ float db_from_ratio(float out, float mx, float inv_mx
 }
 
 // Lean form, from Q itself and its item minimum mn (a normal positive float): max(out) = RN(1/mn) =: mx, and
-// because RN(1/q) is monotone in q the tie set {q : RN(1/q) == mx} is the interval [mn, q_hi] of floats, q_hi at
-// most a few ulp above mn (1 ulp of q moves 1/q by 0.5..2 ulp of the result).  q_hi is found once per item
-// (wave-uniform: IEEE divisions on mn + 1 and + 2 ulp -- two floats 1 ulp apart have reciprocals >= 0.5 ulp apart,
-// so a third cannot share the rounded value); per angle the whole rule is then ONE compare:
-//     tie = (q <= q_hi),   dB = tie ? 0 : -10 log10(2) log2(max(q (1/mn), 1 + 2^-23)).
-// The clamp keeps a non-tied angle strictly negative whatever v_rcp_f32 / the product round to (its true value
-// there is -2.6e-7 dB times a small integer; the clamp gives -5.2e-7: the only place where the fast path is not
-// within v_log_f32's own error of the reference's float arithmetic, and 1e-6 dB below anyone's tolerance).
+// because RN(1/q) is monotone in q the tie set {q : RN(1/q) == mx} is an interval [mn, q_hi] of floats.  Two floats
+// 1 ulp apart have reciprocals at least half an ulp (of the result) apart, so at most TWO consecutive floats can share a
+// rounded reciprocal (a third would need 1/q to sit exactly on a rounding boundary twice: q a power of two twice):
+// q_hi is mn or mn + 1 ulp.  Whether mn + 1 ulp ties is decided exactly without a second division:
+//     RN(1/q) == mx  <=>  |1/q - mx| <= ulp(mx)/2  <=>  |mx q - 1| <= (ulp(mx)/2) q,
+// where r = fma(mx, q, -1) is exact (mx q is within 2^-22 of 1, so the difference has fewer than 24 significant
+// bits) and (ulp(mx)/2) q is a power-of-two multiple of q.  (Equality would put 1/q exactly on the boundary, which
+// needs q to be a power of two; then 1/q is itself a float and the comparison is strict anyway.)
+// Per angle the whole rule is then ONE compare, tie = (q <= q_hi), and
+//     dB = tie ? 0 : -10 log10(2) log2(q inv_up),      inv_up = v_rcp_f32(mn) (1 + 2^-22):
+// the reciprocal is biased UP by two ulp so that every non-tied angle (q >= mn (1 + 2^-23)) has q inv_up > 1 whatever
+// v_rcp_f32 and the product round to, i.e. a strictly negative dB without a clamp; the price is a common -1e-6 dB on
+// the whole row, a quarter of v_log_f32's own error at -30 dB.
 struct LeanNorm {
-    float inv_mn, q_hi;
-    __device__ __forceinline__ explicit LeanNorm(float mn) : inv_mn(__builtin_amdgcn_rcpf(mn)), q_hi(mn)
+    float inv_up, q_hi;
+    __device__ __forceinline__ explicit LeanNorm(float mn) : inv_up(__builtin_amdgcn_rcpf(mn) * 1.00000023841857910f), q_hi(mn)
     {
-        const float mx = 1.0f / mn;
-#pragma unroll
-        for (int k = 1; k <= 2; k++) {
-            const float qk = __int_as_float(__float_as_int(mn) + k);
-            q_hi = (1.0f / qk == mx) ? qk : q_hi;
-        }
+        const float mx = 1.0f / mn;                                        // IEEE: RN(1/mn)
+        const float q1 = __int_as_float(__float_as_int(mn) + 1);           // mn + 1 ulp
+        const float half_ulp = __int_as_float((__float_as_int(mx) & 0x7f800000) - (24 << 23));   // 2^(e - 24)
+        const float r = fmaf(mx, q1, -1.0f);
+        q_hi = (fabsf(r) < half_ulp * q1) ? q1 : mn;
     }
+    // dB of a non-tied angle (meaningless, slightly negative, for a tied one)
+    __device__ __forceinline__ float db_fast(float q) const { return -kDbPerLog2 * __log2f(q * inv_up); }
     __device__ __forceinline__ float db(float q, bool &tie) const
     {
         tie = (q <= q_hi);
-        const float d = -kDbPerLog2 * __log2f(fmaxf(q * inv_mn, 1.00000011920928955f));
-        return tie ? 0.0f : d;
+        return tie ? 0.0f : db_fast(q);
     }
 };
-__device__ __forceinline__ bool lean_norm_ok(float mn) { return (mn >= 1.2e-38f) && (mn < INFINITY); }
+// (mx = 1/mn must be a normal float with ulp(mx)/2 representable: mn between 1e-30 and 1e30 -- the null spectrum of
+// a pre-scaled projector is O(1); anything else takes the general path)
+__device__ __forceinline__ bool lean_norm_ok(float mn) { return (mn >= 1e-30f) && (mn <= 1e30f); }
 
 // Fast path: P % 4 == 0 and P <= 256*CH.  One wave per item, grid-stride over items so that the
 // z table (4*CH angles per lane) is loaded once per wave and stays in registers.  With PEAK the
@@ -272,13 +279,15 @@ template <int N, typename T> struct ChebQ {
 //     general peak_pick.
 // Items whose minimum of Q is not a normal positive float (zero, negative or non-finite null spectrum:
 // non-finite input, in practice) take a slow rolled path that follows the general kernel's semantics literally.
-template <int N, int CH, typename T, bool MULTI>
+template <int N, int CH, typename T, bool MULTI, bool PEAKS>
 __device__ __forceinline__ void lean_scan_item_irregular(const T (&c)[2 * N], float (&qf)[CH][4], const T *__restrict__ ztab,
                                                       float *__restrict__ row, const float *__restrict__ xs,
                                                       float *__restrict__ pk_val_item, float *__restrict__ pk_loc_item,
                                                       int M, int lane);
 
-template <int N, int CH, typename T, bool MULTI>
+// PEAKS = false: spectrum only (the stand-alone MUSIC_lin_array block: same arithmetic, hence the same bits, as the
+// pipeline's kernel); a template parameter rather than nullable pointers, which cost the hot path 30 VGPRs.
+template <int N, int CH, typename T, bool MULTI, bool PEAKS = true>
 __device__ __forceinline__ void lean_scan_item(const T (&c)[2 * N], const T (&zr)[CH][4], const T (&zi)[CH][4],
                                                const T *__restrict__ ztab, float *__restrict__ row,
                                                const float *__restrict__ xs, float *__restrict__ pk_val_item,
@@ -320,74 +329,83 @@ __device__ __forceinline__ void lean_scan_item(const T (&c)[2 * N], const T (&zr
                 store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
                                make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
             }
-            if (pk_val_item) peak_pick<CH>(qf, lane, P, M, xs, pk_val_item, pk_loc_item);
+            if constexpr (PEAKS) peak_pick<CH>(qf, lane, P, M, xs, pk_val_item, pk_loc_item);
         } else {
             int pos = INT_MAX;
 #pragma unroll
             for (int j = 0; j < CH; j++) {
-                float db[4];
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                float t[4], db[4];
+                {
+                    v2f a = {qf[j][0], qf[j][1]}, b = {qf[j][2], qf[j][3]};
+                    a *= nrm.inv_up; b *= nrm.inv_up;                            // v_pk_mul_f32
+                    a = v2f{__log2f(a.x), __log2f(a.y)}; b = v2f{__log2f(b.x), __log2f(b.y)};
+                    a *= -kDbPerLog2; b *= -kDbPerLog2;                          // v_pk_mul_f32
+                    t[0] = a.x; t[1] = a.y; t[2] = b.x; t[3] = b.y;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    bool tie;
-                    db[e] = nrm.db(qf[j][e], tie);
-                    const unsigned long long at_max = __builtin_amdgcn_ballot_w64(tie);
+                    // the tie compare lands in an SGPR pair: the position search is scalar work beside the vector pipe, and
+                    // the same mask drives the select that puts exactly 0 dB on the tied angles (written as
+                    // `tie ? 0.0f : d` the compiler issues a second, inverted compare per angle)
+                    const unsigned long long at_max = __builtin_amdgcn_ballot_w64(qf[j][e] <= nrm.q_hi);
                     const int cand = at_max ? (4 * (int)__builtin_ctzll(at_max) + 256 * j + e) : INT_MAX;
                     pos = min(pos, cand);
+                    asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(db[e]) : "v"(t[e]), "s"(at_max));
                 }
                 store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(db[0], db[1], db[2], db[3]));
             }
             // (the minimum itself always ties, so pos is a valid angle; the clamp only keeps a broken invariant from
             // turning into a wild address)
-            if (lane == 0 && pk_val_item) { pk_val_item[0] = 0.0f; pk_loc_item[0] = xs[min(pos, P - 1)]; }
+            if constexpr (PEAKS) {
+                if (lane == 0) { pk_val_item[0] = 0.0f; pk_loc_item[0] = xs[min(pos, P - 1)]; }
+            }
         }
     } else {
-        lean_scan_item_irregular<N, CH, T, MULTI>(c, qf, ztab, row, xs, pk_val_item, pk_loc_item, M, lane);
+        lean_scan_item_irregular<N, CH, T, MULTI, PEAKS>(c, qf, ztab, row, xs, pk_val_item, pk_loc_item, M, lane);
     }
 }
 
-// rare: follow the general semantics (db_from_ratio, arma index_max) without unrolling
-template <int N, int CH, typename T, bool MULTI>
+// rare (a row whose minimum of Q is not a usable positive float: non-finite input, in practice): follow the general
+// semantics (db_from_ratio, arma index_max / the general peak pick) in ROLLED loops that recompute Q from the table --
+// nothing of this path may cost the hot path a register (unrolled, its sixteen IEEE divisions took the kernel from 112
+// to 152 VGPRs, i.e. from four to three waves per SIMD next to the covariance kernel's 120-VGPR waves: 2.5 us per
+// pipeline step)
+template <int N, int CH, typename T, bool MULTI, bool PEAKS>
 __device__ __forceinline__ void lean_scan_item_irregular(const T (&c)[2 * N], float (&qf)[CH][4], const T *__restrict__ ztab,
-                                                      float *__restrict__ row, const float *__restrict__ xs,
-                                                      float *__restrict__ pk_val_item, float *__restrict__ pk_loc_item,
-                                                      int M, int lane)
+                                                         float *__restrict__ row, const float *__restrict__ xs,
+                                                         float *__restrict__ pk_val_item, float *__restrict__ pk_loc_item,
+                                                         int M, int lane)
 {
     constexpr int P = 256 * CH;
+    (void)qf;
+    auto q_at = [&](int i) { return (float)null_spectrum<N, T>(c, (T)ztab[2 * i], (T)ztab[2 * i + 1]); };
     float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < CH; j++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) mx = fmaxf(mx, 1.0f / qf[j][e]);
+#pragma unroll 1
+    for (int k = 0; k < 4 * CH; k++) mx = fmaxf(mx, 1.0f / q_at(4 * lane + 256 * (k >> 2) + (k & 3)));
     mx = wave_allreduce_max(mx);
     const float inv_mx = __builtin_amdgcn_rcpf(mx);
-    if constexpr (MULTI) {
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) qf[j][e] = db_from_ratio(1.0f / qf[j][e], mx, inv_mx);
-            store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
-                           make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
-        }
-        if (pk_val_item) peak_pick<CH>(qf, lane, P, M, xs, pk_val_item, pk_loc_item);
-        return;
-    }
     float bv = 0.f;
     int bi = INT_MAX;
     float v0 = 0.f;
 #pragma unroll 1
-    for (int j = 0; j < CH; j++)
-#pragma unroll 1
-        for (int e = 0; e < 4; e++) {
-            const int i = 4 * lane + 256 * j + e;
-            const float o = 1.0f / (float)null_spectrum<N, T>(c, (T)ztab[2 * i], (T)ztab[2 * i + 1]);
-            const float db = db_from_ratio(o, mx, inv_mx);
-            row[i] = db;
-            if (i == 0) v0 = db;
-            if (db > -INFINITY && cand_better(db, i, bv, bi)) { bv = db; bi = i; }
-        }
+    for (int k = 0; k < 4 * CH; k++) {
+        const int i = 4 * lane + 256 * (k >> 2) + (k & 3);
+        const float db = db_from_ratio(1.0f / q_at(i), mx, inv_mx);
+        row[i] = db;
+        if (i == 0) v0 = db;
+        if (db > -INFINITY && cand_better(db, i, bv, bi)) { bv = db; bi = i; }
+    }
+    if constexpr (!PEAKS) return;
+    if constexpr (MULTI) {
+        // the general peak pick on the row just written (same wave: its stores are visible to its loads behind the fence)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        peak_pick_stream([&](int p) { return __builtin_nontemporal_load(row + p); }, P, M, xs, pk_val_item, pk_loc_item, lane);
+        return;
+    }
     wave_argbest(bv, bi);
     v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), 0));
-    if (lane == 0 && pk_val_item) {
+    if (lane == 0) {
         pk_val_item[0] = (bi == INT_MAX) ? v0 : bv;
         pk_loc_item[0] = xs[(bi == INT_MAX) ? 0 : bi];
     }
@@ -406,7 +424,7 @@ __device__ __forceinline__ void lean_load_table(const T *__restrict__ ztab, int 
         }
 }
 
-template <int N, int CH, typename T, bool MULTI = false>
+template <int N, int CH, typename T, bool MULTI = false, bool PEAKS = true>
 __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                                float *__restrict__ spec, int n_items,
                                                                const float *__restrict__ xaxis, float *__restrict__ pk_val,
@@ -414,10 +432,10 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
 {
     constexpr int P = 256 * CH;
     __shared__ float xs[P];
-    if (xaxis) {                                      // (pk_val == nullptr: spectrum only, the stand-alone MUSIC block)
+    if constexpr (PEAKS) {
         for (int i = threadIdx.x; i < P; i += blockDim.x) xs[i] = xaxis[i];
+        __syncthreads();
     }
-    __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
     const int n_waves = gridDim.x * (blockDim.x / kWave);
@@ -438,9 +456,8 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
 #pragma unroll
             for (int k = 0; k < 2 * N; k++) c_next[k] = coef[(size_t)nxt * (2 * N) + k];
         }
-        lean_scan_item<N, CH, T, MULTI>(c, zr, zi, ztab, spec + (size_t)item * P, xs,
-                                        pk_val ? pk_val + (size_t)item * M : nullptr,
-                                        pk_val ? pk_loc + (size_t)item * M : nullptr, M, lane);
+        lean_scan_item<N, CH, T, MULTI, PEAKS>(c, zr, zi, ztab, spec + (size_t)item * P, xs, pk_val + (size_t)item * M,
+                                               pk_loc + (size_t)item * M, M, lane);
     }
 }
 
@@ -689,20 +706,29 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
         // without compute 193 us, both 268 us per 262144 items on one box; 8 waves: 247 / 210 / 282), so a third wave
         // per SIMD to fill the DPP-reduction and v_log latencies pays; 16 measured no better
         static const int lwpc = [] { const char *e = getenv("DOA_SCAN_LEAN_WAVES_PER_CU"); return e ? atoi(e) : 12; }();
-        if (lb > cu_count() * lwpc / waves_per_block) lb = cu_count() * lwpc / waves_per_block;
-        dim3 lgrid(lb);
-#define DOA_LEAN_LAUNCH(CH_, MULTI_)                                                                              \
-    hipLaunchKernelGGL((music_scan_peak1_kernel<N, CH_, T, MULTI_>), lgrid, block, 0, st, co, z, sp, n_items, pk.xaxis, \
-                       pk.val, pk.loc, pk.M)
-        if (pk.M <= 1) {
-            if (P == 256) DOA_LEAN_LAUNCH(1, false);
-            else if (P == 512) DOA_LEAN_LAUNCH(2, false);
-            else DOA_LEAN_LAUNCH(4, false);
-        } else {
-            if (P == 256) DOA_LEAN_LAUNCH(1, true);
-            else if (P == 512) DOA_LEAN_LAUNCH(2, true);
-            else DOA_LEAN_LAUNCH(4, true);
+        const int cap = cu_count() * lwpc / waves_per_block;
+        if (lb > cap) {
+            // every wave takes the same number of items (4096 items on a cap of 3072 waves would be one round of 3072 and a
+            // second of 1024 with two thirds of the chip idle: 2048 waves with two items each instead)
+            const int cap_waves = cap * waves_per_block;
+            const int per_wave = (n_items + cap_waves - 1) / cap_waves;
+            const int waves = (n_items + per_wave - 1) / per_wave;
+            lb = (waves + waves_per_block - 1) / waves_per_block;
         }
+        dim3 lgrid(lb);
+#define DOA_LEAN_LAUNCH(CH_, MULTI_, PEAKS_)                                                                       \
+    hipLaunchKernelGGL((music_scan_peak1_kernel<N, CH_, T, MULTI_, PEAKS_>), lgrid, block, 0, st, co, z, sp, n_items,  \
+                       pk.xaxis, pk.val, pk.loc, pk.M)
+#define DOA_LEAN_CH(MULTI_, PEAKS_)                                                                                \
+    do {                                                                                                           \
+        if (P == 256) DOA_LEAN_LAUNCH(1, MULTI_, PEAKS_);                                                          \
+        else if (P == 512) DOA_LEAN_LAUNCH(2, MULTI_, PEAKS_);                                                     \
+        else DOA_LEAN_LAUNCH(4, MULTI_, PEAKS_);                                                                   \
+    } while (0)
+        if (!pk.val) DOA_LEAN_CH(false, false);
+        else if (pk.M == 1) DOA_LEAN_CH(false, true);
+        else DOA_LEAN_CH(true, true);
+#undef DOA_LEAN_CH
 #undef DOA_LEAN_LAUNCH
         return pk.val != nullptr;
     }
