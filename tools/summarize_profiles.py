@@ -39,7 +39,7 @@ def keep(name):
 
 def find_csv(run, suffix):
     fs = glob.glob(os.path.join(src, run, "**", f"*{suffix}"), recursive=True)
-    return fs[0] if fs else None
+    return max(fs, key=os.path.getmtime) if fs else None          # (a re-run leaves the older pid's files next to the new ones)
 
 
 # ---- kernel-trace stats ---------------------------------------------------------------------------------
