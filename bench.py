@@ -56,7 +56,7 @@ def algorithmic_bytes():
             "fused_total": fused, "scan_fused": rec + P_SPEC * 4 + 2 * M_SRC * 4}
 
 
-SCAN_KERNEL = "music_scan_peak1_kernel<4, 4, double, false>"
+SCAN_KERNEL = "music_scan_peak1_kernel<4, 4, double, false, true>"
 COV_KERNEL = "cov_wave_kernel<4, true, 4, true>"
 
 

@@ -70,6 +70,11 @@ DOA_HIP_API int doa_hip_device_count(void);
  * evaluation used by MUSIC / Root-MUSIC / pipeline handles created *after* the call:
  * 64 (default) = double Jacobi + double Horner scan, 32 = float for both.  Item formats stay
  * complex64 in / float32 out either way; Root-MUSIC always finds its roots in double.
+ * 64 is the parity configuration: it is what the tests pin to the fp64 evaluation of the
+ * reference's formulas.  32 is an opt-in, NON-parity mode: it shares the reference's single
+ * precision but not its LAPACK rounding sequence, so at spectrum nulls (where float Q is
+ * cancellation-dominated) it differs from the reference by as much as two correct fp32
+ * implementations differ from each other; it is tested to a loose bound only.
  * Returns DOA_OK or DOA_ERR_INVALID_ARG. */
 DOA_HIP_API int doa_set_internal_precision(int bits);
 DOA_HIP_API int doa_get_internal_precision(void);
