@@ -276,19 +276,28 @@ def sharded_check(doa, torch, dist, world, local_rank, per_rank=512, K=1024, ovl
     dev = torch.device("cuda", local_rank)
 
     def my_samples(begin, end):                     # this rank's shard only, generated in place
-        src = doa.sim_source(N_ANT, 0.45, list(theta), [0.031, 0.047], None, None, 0.1, seed=99)
-        src.seek(begin)
-        bufs = [torch.empty(end - begin, dtype=torch.complex64, device=dev) for _ in range(N_ANT)]
-        src.work_dev(end - begin, [b.data_ptr() for b in bufs], torch.cuda.current_stream())
-        torch.cuda.synchronize()
+        bufs = [torch.zeros(end - begin, dtype=torch.complex64, device=dev) for _ in range(N_ANT)]
+        try:
+            src = doa.sim_source(N_ANT, 0.45, list(theta), [0.031, 0.047], None, None, 0.1, seed=99)
+            src.seek(begin)
+            src.work_dev(end - begin, [b.data_ptr() for b in bufs], torch.cuda.current_stream())
+            torch.cuda.synchronize()
+        except Exception as e:
+            local_error.append(repr(e))
         return bufs
 
+    local_error = []
+
     def compute(bufs, n_local):
-        pipe = doa.music_pipeline(N_ANT, K, ovl, 1, 0.45, 2, P_SPEC, max(n_local, 1))
-        mx = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
-        am = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
-        pipe.work_dev(n_local, [b.data_ptr() for b in bufs], 0, 0, mx.data_ptr(), am.data_ptr(), torch.cuda.current_stream())
-        torch.cuda.synchronize()
+        # never raises: a rank that failed locally must still enter the all_gather its peers are waiting in
+        am = torch.full((n_local, 2), float("nan"), dtype=torch.float32, device=dev)
+        try:
+            pipe = doa.music_pipeline(N_ANT, K, ovl, 1, 0.45, 2, P_SPEC, max(n_local, 1))
+            mx = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
+            pipe.work_dev(n_local, [b.data_ptr() for b in bufs], 0, 0, mx.data_ptr(), am.data_ptr(), torch.cuda.current_stream())
+            torch.cuda.synchronize()
+        except Exception as e:
+            local_error.append(repr(e))
         return am
 
     t0 = time.perf_counter()
@@ -298,6 +307,7 @@ def sharded_check(doa, torch, dist, world, local_rank, per_rank=512, K=1024, ovl
     err = float(max(abs(a[:, 0] - max(theta)).max(), abs(a[:, 1] - min(theta)).max()))     # port 1 is sorted descending
     return {"snapshots": n_total, "ranks": world, "halo_samples": ovl, "shard_samples_rank0": shard.n_samples,
             "gathered_rows": int(a.shape[0]), "max_angle_error_deg": err, "ok": bool(a.shape[0] == n_total and err <= 1.0),
+            **({"rank0_error": local_error[0]} if local_error else {}),
             "seconds_incl_generation": dt}
 
 
