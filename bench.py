@@ -486,6 +486,7 @@ def main():
                                "batch=4096 snapshots/step, complex fp32, SNR 20 dB",
                    "batch": BATCH, "inputs": N_ANT, "snapshot_size": K_SNAP, "pspectrum_len": P_SPEC,
                    "num_targets": M_SRC, "internal_precision": args.precision, "rotating_batches": nbuf, "hip_streams": n_streams,
+                   "input_layout": "N separate stream buffers in HBM, doa_stream_stride_bytes apart (4.5 KiB modulo 8 KiB: no HBM-channel aliasing between streams)",
                    "parallelism": f"snapshot-sharded x{world}, no data-path collective"},
         "pipeline_gbs": ab["fused_total"] * value / world / 1e9,      # fused algorithmic bytes x rate, per GPU
         "pipeline_gbs_unfused_accounting": ab["total"] * value / world / 1e9,   # SURVEY 8(d)'s 41 KB/snapshot

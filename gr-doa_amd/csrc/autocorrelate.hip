@@ -626,7 +626,8 @@ int doa_autocorrelate_work(doa_autocorrelate_t *h, int noutput_items, const void
     if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     const int N = h->inputs;
     const size_t span = (size_t)doa_autocorrelate_input_span(h, noutput_items);
-    const size_t span_al = (span + 1) & ~(size_t)1;  // keep every stream 16-B aligned on the device
+    // distance between the device copies of the streams: 16-B aligned, staggered against the 8 KiB aliasing period
+    const size_t span_al = doa::stream_stride_bytes(span * sizeof(float2)) / sizeof(float2);
     int rc = h->d_in.reserve(span_al * N * sizeof(float2));
     if (rc != DOA_OK) return rc;
     const size_t out_bytes = (size_t)noutput_items * N * N * sizeof(float2);

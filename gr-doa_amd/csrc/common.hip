@@ -115,6 +115,8 @@ int doa_hip_device_count(void)
     return n;
 }
 
+size_t doa_stream_stride_bytes(size_t stream_bytes) { return doa::stream_stride_bytes(stream_bytes); }
+
 int doa_set_internal_precision(int bits)
 {
     if (bits != 32 && bits != 64) {

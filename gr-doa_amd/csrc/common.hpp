@@ -53,6 +53,11 @@ struct PinnedBuf {
 
 int internal_precision_bits();  // 32 or 64 (doa_set_internal_precision)
 
+// Distance between the device copies of consecutive input streams (doa_stream_stride_bytes): the stream size rounded up
+// to 8 KiB plus 4.5 KiB, so that stream k starts 4.5 k KiB further into the 8 KiB period than stream 0 -- sixteen
+// distinct multiples of 512 B for sixteen streams (9 is odd).  See include/doa_hip.h for the measurement.
+inline size_t stream_stride_bytes(size_t stream_bytes) { return ((stream_bytes + 8191) & ~(size_t)8191) + 4608; }
+
 // ---- device-side wave primitives (wave = 64 lanes on gfx950) -----------------------------------
 constexpr int kWave = 64;
 

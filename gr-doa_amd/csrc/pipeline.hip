@@ -243,7 +243,8 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
     size_t chunk = ((size_t)32 << 20) / (nonoverlap * N * sizeof(float2));
     chunk = chunk < 1 ? 1 : (chunk > (size_t)noutput_items ? (size_t)noutput_items : chunk);
     const size_t span_max = (chunk - 1) * nonoverlap + h->K;
-    const size_t span_al = (span_max + 1) & ~(size_t)1;          // every stream stays 16-B aligned on the device
+    // distance between the device copies of the streams: 16-B aligned and staggered against the 8 KiB aliasing period
+    const size_t span_al = doa::stream_stride_bytes(span_max * sizeof(float2)) / sizeof(float2);
     int rc = h->d_res.reserve((size_t)h->max_batch * M * 2 * sizeof(float));
     for (auto &b : h->d_in)
         if (rc == DOA_OK) rc = b.reserve(span_al * N * sizeof(float2));

@@ -60,6 +60,7 @@ SIGNATURES = {
     "doa_last_error": (C.c_char_p, []),
     "doa_hip_abi_version": (C.c_int, []),
     "doa_hip_device_count": (C.c_int, []),
+    "doa_stream_stride_bytes": (C.c_size_t, [C.c_size_t]),
     "doa_set_internal_precision": (C.c_int, [C.c_int]),
     "doa_get_internal_precision": (C.c_int, []),
     "doa_autocorrelate_create": (_vp, [C.c_int, C.c_int, C.c_int, C.c_int]),

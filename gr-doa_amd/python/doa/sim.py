@@ -109,4 +109,24 @@ def make_batch_streams_torch(num_ant_ele: int, snapshot_size: int, batch: int, n
     wi = torch.randn(x.shape, generator=g, device=device, dtype=torch.float64)
     x = x + (sigma / (2.0 ** 0.5)) * torch.complex(wr, wi)
     x = x.to(torch.complex64).permute(1, 0, 2).reshape(num_ant_ele, batch * K).contiguous()
-    return [x[n].contiguous() for n in range(num_ant_ele)], thetas.cpu().numpy()
+    return stream_slab_torch([x[n] for n in range(num_ant_ele)]), thetas.cpu().numpy()
+
+
+def stream_slab_torch(streams):
+    """Copies N equally long complex64 device tensors into ONE allocation at the distance the library recommends
+    (doa_stream_stride_bytes: streams whose addresses agree modulo 8 KiB share HBM channels; include/doa_hip.h) and
+    returns the N views.  The layout a device-resident producer should use for the streams it hands to
+    autocorrelate / music_pipeline.work_dev."""
+    import torch
+    from ._lib import lib
+
+    n, nbytes = len(streams), streams[0].numel() * 8
+    stride = int(lib.doa_stream_stride_bytes(nbytes))
+    slab = torch.empty(n * stride + 4096, dtype=torch.uint8, device=streams[0].device)
+    off0 = (-slab.data_ptr()) % 4096
+    out = []
+    for k, s in enumerate(streams):
+        v = slab[off0 + k * stride: off0 + k * stride + nbytes].view(torch.complex64)
+        v.copy_(s)
+        out.append(v)
+    return out

@@ -34,6 +34,21 @@ for b in range(args.nbuf):
     else:                                        # M sources at SNR 20 dB, a random direction set per snapshot
         s_, _ = doa.sim.make_batch_streams_torch(N, K, B, 0.5, M, 20.0, seed=b)     # B*K >= (B-1)*STEP + K samples
         streams.append(s_)
+PAD = int(os.environ.get("BENCH_CH_PAD", "-1"))        # >= 0: the N streams of a buffer set in one slab, PAD bytes between them
+if PAD >= 0:
+    assert PAD % 16 == 0
+    padded = []
+    for s_ in streams:
+        nbytes = s_[0].numel() * 8
+        slab = torch.empty(N * (nbytes + PAD) + 4096, dtype=torch.uint8, device="cuda")
+        off0 = (-slab.data_ptr()) % 4096
+        chans = []
+        for n in range(N):
+            v = slab[off0 + n * (nbytes + PAD): off0 + n * (nbytes + PAD) + nbytes].view(torch.complex64)
+            v.copy_(s_[n])
+            chans.append(v)
+        padded.append(chans)
+    streams = padded
 ptrs = [[t.data_ptr() for t in s] for s in streams]
 cov = [torch.empty((B, N * N), dtype=torch.complex64, device="cuda") for _ in range(args.nbuf)]
 spec = [torch.empty((B, P), dtype=torch.float32, device="cuda") for _ in range(args.nbuf)]
