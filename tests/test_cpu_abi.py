@@ -98,3 +98,15 @@ def test_sharding_helper():
     for a, b in zip(shards, shards[1:]):
         assert a.sample_end - b.sample_begin == ovl
     assert sharding.job_throughput([10, 10], [1.0, 2.0]) == 10.0
+
+
+def test_stream_stride_rule():
+    """doa_stream_stride_bytes: at least the stream, 16-byte aligned, and 4.5 KiB into the 8 KiB period the HBM channels
+    repeat with, so that up to 16 streams laid out with it start at 16 distinct offsets modulo 8 KiB (include/doa_hip.h)."""
+    from doa import _lib
+    f = _lib.lib.doa_stream_stride_bytes
+    for nbytes in (0, 8, 8 * 1024 * 4096, 8 * 1000 * 37, 8191, 8192, 8193, 123456792):
+        s = int(f(nbytes))
+        assert s >= nbytes and s % 16 == 0 and s % 8192 == 4608 and s - nbytes < 8192 + 4608 + 1
+    s = int(f(8 * 1024 * 4096))
+    assert len({(k * s) % 8192 for k in range(16)}) == 16
