@@ -22,7 +22,9 @@ i + 2: three or four streams keep that from stalling the covariance of step i + 
 of three by 1-3 us per step more often than not).
 
 Multi-GPU (weak scaling): snapshots are independent, so every rank owns its own batch and there is
-no data-path collective; value = (steps * batch * world) / max-over-ranks time.  After the timed region the
+no data-path collective; value = (steps * batch * world) / max-over-ranks time.  Timing: barrier + synchronize, clock
+on, K steps, synchronize, clock off, barrier, MAX over ranks of the per-rank times (the closing collective's own latency is
+not charged to the steps; the slowest rank decides).  After the timed region the
 ranks also run the product's sharded driver (doa.distributed.run_sharded: one stream cut into per-rank
 shards with their overlap halo, results gathered over RCCL) and rank 0 reports it as "sharded_run".
 """
@@ -411,12 +413,17 @@ def main():
     torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
+    # Timed region: barrier + synchronize on both sides.  Each rank stops its clock when ITS K steps have completed
+    # (synchronize), the closing barrier follows, and the job's time is the MAX over ranks -- the time from the common
+    # start to the slowest rank's completion, without the closing collective's own latency (tens of microseconds of
+    # RCCL launch + ring on 8 GPUs would otherwise be charged to a 20-step region of ~0.6 ms).
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    barrier()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    barrier()
     if dist is not None:
         elapsed = doa.distributed.max_over_ranks(elapsed, device="cuda", dist=dist)
 
