@@ -8,6 +8,8 @@ reduction across snapshots), so an N-rank job is
                          sample: the halo GNU Radio's set_history(overlap+1) hands the block
                          (reference lib/autocorrelate_impl.cc:56-57; `doa.sharding`);
     per-rank pipeline    the rank's own device pipeline over its shard (injected as `compute`);
+    (shard scatter       optional, `scatter_shards`: when ONE rank ingests the whole stream it sends every other rank its
+                         shard, halo included, point to point;)
     result gather        optional: one all_gather of the per-snapshot results (angles: a few bytes
                          per snapshot; RCCL over xGMI on GPUs, gloo on CPU).  Shards differ by at
                          most one snapshot, so the gather pads to the largest shard.
@@ -71,6 +73,42 @@ def gather_results(local, shards: Sequence[sharding.Shard], dist=None):
     dist.all_gather_into_tensor(out, buf.contiguous())
     parts = [out[r * biggest: r * biggest + shards[r].n_snapshots] for r in range(world)]
     return torch.cat(parts, dim=0)
+
+
+def scatter_shards(streams, n_streams: int, n_snapshots: int, snapshot_size: int, overlap_size: int, *,
+                   src: int = 0, device=None, dist=None):
+    """The ingest rank hands every rank its shard: point-to-point sends of [shard samples incl. the overlap halo] per
+    stream from rank `src` (which holds the N whole streams as complex64 torch tensors; the other ranks pass None), all
+    posted at once (`batch_isend_irecv`: on an 8-GPU node the 7 shards leave over 7 xGMI links in parallel).  This is
+    the only exchange the path has on its input side, and a job whose ranks ingest their own shards never needs it.
+    Returns this rank's list of N complex64 tensors on `device` (CPU for gloo)."""
+    import torch
+    dist = dist or _dist()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    shards = sharding.all_shards(n_snapshots, world, snapshot_size, overlap_size)
+    gloo = dist.get_backend() == "gloo"
+    dev = torch.device("cpu") if gloo else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    me = shards[rank]
+    if rank == src:
+        if streams is None or len(streams) != n_streams:
+            raise ValueError("the ingest rank must hold all n_streams streams")
+        ops, keep = [], []
+        for r, sh in enumerate(shards):
+            if r == src or sh.n_samples == 0:
+                continue
+            for k in range(n_streams):
+                piece = torch.view_as_real(streams[k][sh.sample_begin:sh.sample_end].to(dev).contiguous())
+                keep.append(piece)
+                ops.append(dist.P2POp(dist.isend, piece, r))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return [streams[k][me.sample_begin:me.sample_end].to(dev).contiguous() for k in range(n_streams)]
+    mine = [torch.empty((me.n_samples, 2), dtype=torch.float32, device=dev) for _ in range(n_streams)]
+    if me.n_samples:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, t, src) for t in mine]):
+            w.wait()
+    return [torch.view_as_complex(t) for t in mine]
 
 
 def run_sharded(streams, n_snapshots: int, snapshot_size: int, overlap_size: int,

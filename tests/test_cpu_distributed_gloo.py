@@ -55,6 +55,47 @@ def _worker(rank, world, port, K, ovl, n_total, out_dir, by_callable):
     dist.destroy_process_group()
 
 
+def _scatter_worker(rank, world, port, K, ovl, n_total, out_dir):
+    sys.path[:0] = [os.path.join(ROOT, "gr-doa_amd", "python"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import doa_oracle as oracle
+    from doa import distributed, sharding
+    from test_cpu_oracle_pins import sim
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    distributed.init_process_group("gloo")
+    N, S = 3, K - ovl
+    x = None
+    if rank == 0:                                   # only the ingest rank ever holds the stream
+        x = sim.make_streams(N, (n_total - 1) * S + K, [55.0], 0.5, snr_db=10.0, seed=9)
+    streams = [torch.from_numpy(np.ascontiguousarray(x[k])) for k in range(N)] if rank == 0 else None
+    mine = distributed.scatter_shards(streams, N, n_total, K, ovl, src=0)
+    sh = sharding.shard_snapshots(n_total, world, rank, K, ovl)
+    assert len(mine) == N and all(t.shape[0] == sh.n_samples and t.dtype == torch.complex64 for t in mine)
+
+    def compute(shard_streams, n_local):
+        xs = np.stack([s.numpy() for s in shard_streams]) if n_local else np.zeros((N, 0), np.complex64)
+        R = oracle.autocorrelate(xs, K, ovl, 0, n_local) if n_local else np.zeros((0, N * N), np.complex64)
+        return torch.from_numpy(np.stack([R.real, R.imag], axis=-1).astype(np.float32))
+
+    # the scattered shard is handed over as "this rank's slice": a callable that ignores the (global) range it is asked for
+    got, _ = distributed.run_sharded(lambda b, e: mine, n_total, K, ovl, compute)
+    if rank == 0:
+        a = got.numpy()
+        full = oracle.autocorrelate(x, K, ovl, 0, n_total)
+        np.save(os.path.join(out_dir, "scatter_ok.npy"),
+                np.array([float(np.array_equal((a[..., 0] + 1j * a[..., 1]).astype(np.complex64), full)), float(a.shape[0])]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,K,ovl,n_total", [(2, 128, 32, 21), (3, 64, 0, 4), (3, 32, 31, 2)])
+def test_ingest_rank_scatters_shards_with_halo(tmp_path, world, K, ovl, n_total):
+    """one rank ingests, point-to-point scatter of the shards (halo included), per-rank pipeline, gather."""
+    from doa import launch
+    mp.spawn(_scatter_worker, args=(world, launch.free_port(), K, ovl, n_total, str(tmp_path)), nprocs=world, join=True)
+    ok, rows = np.load(os.path.join(str(tmp_path), "scatter_ok.npy"))
+    assert ok == 1.0 and rows == n_total
+
+
 @pytest.mark.parametrize("K,ovl,n_total,by_callable", [(256, 64, 37, False), (128, 0, 10, True), (64, 48, 5, True)])
 def test_two_rank_run_sharded_equals_unsharded(tmp_path, K, ovl, n_total, by_callable):
     from doa import launch
