@@ -128,6 +128,28 @@ doa_antenna_correction_t *doa_antenna_correction_create(int num_ant_ele, const c
     return h;
 }
 
+doa_antenna_correction_t *doa_antenna_correction_create_gains(int num_ant_ele, const float *gains_re_im)
+{
+    doa::clear_error();
+    if (num_ant_ele <= 0 || num_ant_ele > DOA_MAX_ANT_ELE) {
+        doa::set_error("antenna_correction: num_ant_ele=%d outside 1..%d", num_ant_ele, DOA_MAX_ANT_ELE);
+        return nullptr;
+    }
+    if (!gains_re_im) { doa::set_error("antenna_correction: gains_re_im is NULL"); return nullptr; }
+    int dev = 0;
+    if (doa::ensure_device(&dev) != DOA_OK) return nullptr;
+    auto *h = new (std::nothrow) doa_antenna_correction();
+    if (!h) { doa::set_error("out of memory"); return nullptr; }
+    h->N = num_ant_ele; h->device = dev;
+    memcpy(h->gains, gains_re_im, sizeof(float) * 2 * num_ant_ele);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        doa::set_error("antenna_correction: hipStreamCreate failed");
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
 void doa_antenna_correction_destroy(doa_antenna_correction_t *h)
 {
     if (!h) return;

@@ -86,6 +86,7 @@ SIGNATURES = {
     "doa_rootMUSIC_linear_array_debug": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "doa_rootMUSIC_linear_array_work_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "doa_antenna_correction_create": (_vp, [C.c_int, C.c_char_p]),
+    "doa_antenna_correction_create_gains": (_vp, [C.c_int, _vp]),
     "doa_antenna_correction_destroy": (None, [_vp]),
     "doa_antenna_correction_gains": (C.c_int, [_vp, _vp]),
     "doa_antenna_correction_work": (C.c_int, [_vp, C.c_int, _vpp, _vpp]),

@@ -159,6 +159,47 @@ class antenna_correction(_Block):
                                                          ptr_array(d_out_ptrs), _stream_ptr(stream)))
 
 
+def read_phase_config(filename):
+    """The phase file of phase_correct_hier, parsed the way python/phase_correct_hier.py:33-45 parses it: every line
+    that float() accepts AND whose value is truthy is a phase (so a line reading 0 is dropped, like a comment line)."""
+    def ok(text):
+        try:
+            return float(text)
+        except ValueError:
+            return False
+    with open(filename, "r") as f:
+        lines = [line.rstrip("\n") for line in f]
+    return [float(t) for t in lines if ok(t)]
+
+
+class phase_correct_hier(antenna_correction):
+    """doa.phase_correct_hier(num_ports, config_filename) -- the reference's hier block (python/phase_correct_hier.py:
+    52-104): stream 0 passes through, stream p+1 is multiplied by exp(1j*phase_p), phases read from a text file.  Here one
+    launch of the per-stream complex-gain kernel (antenna_correction's), or no launch at all when the gains are folded
+    into the covariance kernel (autocorrelate.fuse_antenna_correction(self.gains())).  The reference writes its message to
+    stderr and exits; this raises ValueError with the same text."""
+
+    def __init__(self, num_ports=2, config_filename=""):
+        _Block.__init__(self)
+        self.num_ports = self.num_ant_ele = int(num_ports)
+        self.config_filename = config_filename
+        try:
+            open(config_filename, "r").close()
+        except (OSError, IOError):
+            raise ValueError("Configuration " + str(config_filename) + ", not valid")
+        self.phases = read_phase_config(config_filename)
+        if len(self.phases) != self.num_ports - 1:
+            raise ValueError("Configuration " + str(config_filename) + ". Not valid number of phase estimates")
+        # numpy.exp(1j*phase) in double, handed to multiply_const_vcc as gr_complex (:93-94)
+        g = np.array([1.0 + 0.0j] + [np.exp(1j * ph) for ph in self.phases], dtype=np.complex128).astype(_C64)
+        h = lib.doa_antenna_correction_create_gains(self.num_ports, _vp(np.ascontiguousarray(g)))
+        if not h:
+            raise _lib.DoaError(-1, _lib.last_error() or "phase_correct_hier: create failed")
+        self._h = h
+        self.in_sig = [(_C64, 1)] * self.num_ports
+        self.out_sig = [(_C64, 1)] * self.num_ports
+
+
 class MUSIC_lin_array(_Block):
     """doa.MUSIC_lin_array(norm_spacing, num_targets, inputs, pspectrum_len) — gr::sync_block
     (reference lib/MUSIC_lin_array_impl.cc:47-87)."""

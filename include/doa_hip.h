@@ -205,6 +205,10 @@ DOA_HIP_API int doa_rootMUSIC_linear_array_work_dev(doa_rootMUSIC_linear_array_t
 typedef struct doa_antenna_correction doa_antenna_correction_t;
 
 DOA_HIP_API doa_antenna_correction_t *doa_antenna_correction_create(int num_ant_ele, const char *config_filename);
+/* The same block from explicit per-stream complex gains (re, im interleaved) instead of a file: what
+ * python/phase_correct_hier.py:90-97 builds out of multiply_const_vcc blocks (stream 0 untouched, stream p+1 times
+ * exp(j phase_p)); the Python mirror doa.phase_correct_hier parses the phase file as the reference does and calls this. */
+DOA_HIP_API doa_antenna_correction_t *doa_antenna_correction_create_gains(int num_ant_ele, const float *gains_re_im);
 DOA_HIP_API void doa_antenna_correction_destroy(doa_antenna_correction_t *h);
 /* Copies the num_ant_ele complex gains (re, im interleaved) out; returns num_ant_ele. */
 DOA_HIP_API int doa_antenna_correction_gains(const doa_antenna_correction_t *h, float *gains_re_im);

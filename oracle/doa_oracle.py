@@ -74,6 +74,30 @@ def antenna_correction(input_items: np.ndarray, gains: np.ndarray) -> np.ndarray
     return (np.asarray(gains, dtype=_C64)[:, None] * x).astype(_C64)
 
 
+def phase_correct_phases(config_text: str):
+    """python/phase_correct_hier.py:33-45 (read_config_file): lines split at '\n'; `filter(f, lines)` keeps a line when
+    f(line) = float(line) is truthy -- a line that does not parse gives False, and so does a line that parses to 0.0."""
+    out = []
+    for line in config_text.split("\n"):
+        try:
+            v = float(line)
+        except ValueError:
+            continue
+        if v:
+            out.append(v)
+    return out
+
+
+def phase_correct(input_items: np.ndarray, phases) -> np.ndarray:
+    """python/phase_correct_hier.py:86-104: port 0 -> blocks.copy; port p+1 -> multiply_const_vcc((numpy.exp(1j*phase_p),)),
+    i.e. a complex<float> product with the double-precision exponential rounded to gr_complex."""
+    x = np.asarray(input_items, dtype=_C64)
+    if len(phases) != x.shape[0] - 1:
+        raise ValueError("Not valid number of phase estimates")
+    g = np.array([1.0 + 0.0j] + [np.exp(1j * float(p)) for p in phases], dtype=np.complex128).astype(_C64)
+    return (g[:, None] * x).astype(_C64)
+
+
 # --------------------------------------------------------------------------------------------
 # autocorrelate  (lib/autocorrelate_impl.cc)
 # --------------------------------------------------------------------------------------------

@@ -30,6 +30,11 @@ EXPECT = {
         params={"num_inputs": None, "config_filename": "/tmp/antenna.cfg"},
         checks=[],
         sinks=[("complex", None, "$num_inputs")], sources=[("complex", None, "$num_inputs")]),
+    "phase_correct_hier": dict(
+        make="doa.phase_correct_hier(num_ports=$num_ports, config_filename=$config_filename)",
+        params={"num_ports": "2", "config_filename": "/tmp/phases.cfg"},
+        checks=[],
+        sinks=[("complex", None, "$num_ports")], sources=[("complex", None, "$num_ports")]),
     "doa_calibrate_lin_array": dict(
         make="doa.calibrate_lin_array($norm_spacing, $num_ant_ele, $pilot_angle)",
         params={"norm_spacing": "0.5", "num_ant_ele": "4", "pilot_angle": "45.0"},
