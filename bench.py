@@ -427,6 +427,23 @@ def main():
     if dist is not None:
         elapsed = doa.distributed.max_over_ranks(elapsed, device="cuda", dist=dist)
 
+    # Secondary figure, never `value`: the same steps with no spectrum pointer (the fused block with only its angle port
+    # connected: the 4 KiB row per snapshot is neither converted to dB nor written).
+    def step_angles(i):
+        b, k = i % nbuf, i % n_streams
+        pipes[k].work_dev(BATCH, in_ptrs[b], cov[b].data_ptr(), 0, mx[b].data_ptr(), am[b].data_ptr(), hip_streams[k])
+    for i in range(8):
+        step_angles(i)
+    torch.cuda.synchronize()
+    ta = time.perf_counter()
+    for i in range(args.steps):
+        step_angles(i)
+    torch.cuda.synchronize()
+    angles_elapsed = time.perf_counter() - ta
+    for i in range(n_streams):                        # leave full results (spectra included) in the buffers the checks read
+        step(args.steps - 1 - i)
+    torch.cuda.synchronize()
+
     # Not part of the timed region (snapshots are independent: the path has no data-path collective): the sharded
     # run itself, product code (doa.distributed.run_sharded) -- ONE stream of world x 512 overlapping windows is cut
     # into contiguous per-rank shards with their overlap halo, every rank generates only its own samples (seekable
@@ -484,6 +501,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "angles_only_mode": {"value": args.steps * BATCH / angles_elapsed, "unit": "snapshots/s (this rank)",
+                             "ms_per_step": angles_elapsed / args.steps * 1e3,
+                             "note": "secondary: same steps with no spectrum output requested (spectrum neither converted to dB nor written); not the headline"},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -37,7 +37,7 @@ int launch_calibrate(int N, int n_items, const void *d_R, const void *d_pilot, v
 struct PeakTables;
 int launch_music_scan(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec, void *d_q,
                       hipStream_t st, const PeakTables *peaks = nullptr, void *d_max = nullptr,
-                      void *d_argmax = nullptr, bool *peaks_done = nullptr);
+                      void *d_argmax = nullptr, bool *peaks_done = nullptr, bool store_spectrum = true);
 
 // K5 (find_local_max.hip)
 struct PeakTables {

@@ -64,13 +64,15 @@ int MusicTables::build(float norm_spacing_, int num_targets, int num_ant_ele, in
 DOA_SCAN_SIZES(DOA_SCAN_EXTERN)
 
 int launch_music_scan(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec, void *d_q,
-                      hipStream_t st, const PeakTables *peaks, void *d_max, void *d_argmax, bool *peaks_done)
+                      hipStream_t st, const PeakTables *peaks, void *d_max, void *d_argmax, bool *peaks_done,
+                      bool store_spectrum)
 {
     if (peaks_done) *peaks_done = false;
     if (n_items <= 0) return DOA_OK;
     ScanPeakArgs pk;
     if (peaks && d_max && d_argmax && peaks->L == t.P) {
         pk.xaxis = peaks->d_x.as<float>(); pk.val = (float *)d_max; pk.loc = (float *)d_argmax; pk.M = peaks->M;
+        pk.store = store_spectrum;
     }
     bool done = false;
     // compiled polynomial sizes: 2, 3, 4, 6, 8, 12, 16 (an array of n elements uses the next size up

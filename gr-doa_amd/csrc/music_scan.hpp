@@ -10,6 +10,7 @@ struct ScanPeakArgs {           // optional fused K5
     const float *xaxis = nullptr;
     float *val = nullptr, *loc = nullptr;
     int M = 0;
+    bool store = true;          // false: nobody wants the spectrum (angles-only pipeline call); d_spec is scratch then
 };
 
 // returns true when the fused peak pick ran (fast paths only)

@@ -287,7 +287,11 @@ __device__ __forceinline__ void lean_scan_item_irregular(const T (&c)[2 * N], fl
 
 // PEAKS = false: spectrum only (the stand-alone MUSIC_lin_array block: same arithmetic, hence the same bits, as the
 // pipeline's kernel); a template parameter rather than nullable pointers, which cost the hot path 30 VGPRs.
-template <int N, int CH, typename T, bool MULTI, bool PEAKS = true>
+// STORE = false (with PEAKS): the angles-only mode of the pipeline -- nobody wants the spectrum (the fused block with only
+// its angle port connected), so the row is neither converted to dB (num_max_vals == 1: the answer is the first angle
+// whose rounded reciprocal ties with the maximum, and its value is 0 dB by construction) nor written; rows on the
+// irregular path use `row` as scratch.
+template <int N, int CH, typename T, bool MULTI, bool PEAKS = true, bool STORE = true>
 __device__ __forceinline__ void lean_scan_item(const T (&c)[2 * N], const T (&zr)[CH][4], const T (&zi)[CH][4],
                                                const T *__restrict__ ztab, float *__restrict__ row,
                                                const float *__restrict__ xs, float *__restrict__ pk_val_item,
@@ -326,12 +330,24 @@ __device__ __forceinline__ void lean_scan_item(const T (&c)[2 * N], const T (&zr
                     bool tie;
                     qf[j][e] = nrm.db(qf[j][e], tie);
                 }
-                store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
-                               make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
+                if constexpr (STORE)
+                    store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
+                                   make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
             }
             if constexpr (PEAKS) peak_pick<CH>(qf, lane, P, M, xs, pk_val_item, pk_loc_item);
         } else {
             int pos = INT_MAX;
+            if constexpr (!STORE) {
+                // angles only: the tie compare and the scalar position search, nothing else
+#pragma unroll
+                for (int j = 0; j < CH; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const unsigned long long at_max = __builtin_amdgcn_ballot_w64(qf[j][e] <= nrm.q_hi);
+                        const int cand = at_max ? (4 * (int)__builtin_ctzll(at_max) + 256 * j + e) : INT_MAX;
+                        pos = min(pos, cand);
+                    }
+            } else
 #pragma unroll
             for (int j = 0; j < CH; j++) {
                 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -424,7 +440,7 @@ __device__ __forceinline__ void lean_load_table(const T *__restrict__ ztab, int 
         }
 }
 
-template <int N, int CH, typename T, bool MULTI = false, bool PEAKS = true>
+template <int N, int CH, typename T, bool MULTI = false, bool PEAKS = true, bool STORE = true>
 __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                                float *__restrict__ spec, int n_items,
                                                                const float *__restrict__ xaxis, float *__restrict__ pk_val,
@@ -456,8 +472,8 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
 #pragma unroll
             for (int k = 0; k < 2 * N; k++) c_next[k] = coef[(size_t)nxt * (2 * N) + k];
         }
-        lean_scan_item<N, CH, T, MULTI, PEAKS>(c, zr, zi, ztab, spec + (size_t)item * P, xs, pk_val + (size_t)item * M,
-                                               pk_loc + (size_t)item * M, M, lane);
+        lean_scan_item<N, CH, T, MULTI, PEAKS, STORE>(c, zr, zi, ztab, spec + (size_t)item * P, xs, pk_val + (size_t)item * M,
+                                                      pk_loc + (size_t)item * M, M, lane);
     }
 }
 
@@ -726,6 +742,15 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
         else DOA_LEAN_LAUNCH(4, MULTI_, PEAKS_);                                                                   \
     } while (0)
         if (!pk.val) DOA_LEAN_CH(false, false);
+        else if (!pk.store) {
+            // angles only (sp is scratch for irregular rows)
+#define DOA_LEAN_NOSTORE(CH_, MULTI_)                                                                              \
+    hipLaunchKernelGGL((music_scan_peak1_kernel<N, CH_, T, MULTI_, true, false>), lgrid, block, 0, st, co, z, sp, n_items, \
+                       pk.xaxis, pk.val, pk.loc, pk.M)
+            if (pk.M == 1) { if (P == 256) DOA_LEAN_NOSTORE(1, false); else if (P == 512) DOA_LEAN_NOSTORE(2, false); else DOA_LEAN_NOSTORE(4, false); }
+            else { if (P == 256) DOA_LEAN_NOSTORE(1, true); else if (P == 512) DOA_LEAN_NOSTORE(2, true); else DOA_LEAN_NOSTORE(4, true); }
+#undef DOA_LEAN_NOSTORE
+        }
         else if (pk.M == 1) DOA_LEAN_CH(false, true);
         else DOA_LEAN_CH(true, true);
 #undef DOA_LEAN_CH

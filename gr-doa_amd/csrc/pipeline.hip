@@ -36,9 +36,13 @@ struct doa_music_pipeline {
 
 // K1 -> EVD -> scan (+ peak) for n items on `st`; coefficient records at item offset `coef_off` of the
 // handle's workspace (chunks in flight on different streams must not share records).
+// `spec` == nullptr: nobody wants the spectrum (angles-only call): the handle's own buffer serves as scratch and the lean
+// scan kernel neither converts the row to dB nor writes it.
 static int run_dev(doa_music_pipeline *h, int n, const void *const *d_in, void *cov, void *spec, void *mx, void *am,
                    size_t item_off, hipStream_t st, int lane = 0)
 {
+    const bool store_spec = (spec != nullptr);
+    if (!spec) spec = static_cast<char *>(h->d_spec.p) + item_off * h->peaks.L * sizeof(float);
     const unsigned skip = ~h->stages & 7u;      // doa_music_pipeline_set_stages (profiling aid; 0 in production)
     int rc = DOA_OK;
     if (!(skip & 1)) rc = doa::launch_autocorrelate(h->N, h->K, h->ovl, h->avg, n, d_in, cov, st,
@@ -51,7 +55,7 @@ static int run_dev(doa_music_pipeline *h, int n, const void *const *d_in, void *
     if (rc != DOA_OK) return rc;
     bool peaks_done = false;
     if (skip & 4) return n;
-    rc = doa::launch_music_scan(h->music, h->bits, n, coef, spec, nullptr, st, &h->peaks, mx, am, &peaks_done);
+    rc = doa::launch_music_scan(h->music, h->bits, n, coef, spec, nullptr, st, &h->peaks, mx, am, &peaks_done, store_spec);
     if (rc != DOA_OK) return rc;
     if (peaks_done) return n;
     if (doa::find_local_max_fast_ok(h->peaks.L, spec)) {
@@ -162,7 +166,7 @@ int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput_items, cons
     if (noutput_items == 0) return 0;
     if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     void *cov = d_cov_out ? d_cov_out : h->d_cov.p;
-    void *spec = d_spectrum_out ? d_spectrum_out : h->d_spec.p;
+    void *spec = d_spectrum_out;                       // NULL = angles only (run_dev)
     return run_dev(h, noutput_items, d_input_items, cov, spec, d_max_out, d_argmax_out, 0,
                    static_cast<hipStream_t>(hip_stream));
 }
@@ -223,7 +227,7 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
             char *dr = h->d_res.as<char>();
             float *d_mx = reinterpret_cast<float *>(dr), *d_am = reinterpret_cast<float *>(dr + off_am);
             void *d_cov = cov_out ? (void *)(dr + off_cov) : h->d_cov.p;
-            void *d_spec = spectrum_out ? (void *)(dr + off_spec) : h->d_spec.p;
+            void *d_spec = spectrum_out ? (void *)(dr + off_spec) : nullptr;            // NULL = angles only
             rc = run_dev(h, noutput_items, d_ptrs, d_cov, d_spec, d_mx, d_am, 0, st, 0);
             if (rc < 0) return rc;
             // (the staging buffer is free again: the upload was enqueued before the kernels on the same stream, and
@@ -265,7 +269,7 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
             d_ptrs[k] = dst;
         }
         float2 *cov = h->d_cov.as<float2>() + s0 * N * N;
-        float *spec = h->d_spec.as<float>() + s0 * P;
+        float *spec = spectrum_out ? h->d_spec.as<float>() + s0 * P : nullptr;         // NULL = angles only
         rc = run_dev(h, (int)n, d_ptrs, cov, spec, d_mx + s0 * M, d_am + s0 * M, s0, st, lane);
         if (rc < 0) break;
         if (cov_out)
