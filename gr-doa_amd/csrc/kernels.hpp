@@ -54,5 +54,8 @@ int launch_find_local_max(const PeakTables &t, int n_items, const void *d_in, vo
 // d_roots (optional, diagnostics): the 2N-2 roots found per item as double2, in the kernel's lane order.
 int launch_root_music(int N, int M, float norm_spacing, int n_items, const void *d_coef, void *d_out,
                       void *d_status, hipStream_t st, void *d_roots = nullptr);
+// the selection stage of K6 alone, on caller-supplied roots (n_items x (2N-2) double2): diagnostics
+int launch_root_select(int N, int M, float norm_spacing, int n_items, const void *d_roots, void *d_out, void *d_status,
+                       hipStream_t st);
 
 }  // namespace doa

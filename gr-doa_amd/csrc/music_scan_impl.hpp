@@ -477,6 +477,14 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
     }
 }
 
+}  // namespace doa
+#ifdef DOA_LAB
+#include "music_scan_lab.hpp"
+#include <algorithm>
+#include <vector>
+#endif
+namespace doa {
+
 // Long spectra (P % 4 == 0, any length): one wave per item, 4 consecutive angles per lane per 256-angle
 // chunk, chunks in a ROLLED loop, Q parked as float in the output row between the two passes (minimum first,
 // then dB in place), so that nothing of the row lives in registers: ~100 VGPRs where the unrolled CH = 16 kernel needs 430-511 (one wave per
@@ -741,6 +749,43 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
         else if (P == 512) DOA_LEAN_LAUNCH(2, MULTI_, PEAKS_);                                                     \
         else DOA_LEAN_LAUNCH(4, MULTI_, PEAKS_);                                                                   \
     } while (0)
+#ifdef DOA_LAB
+        if constexpr (N == 4 && sizeof(T) == 8) {
+            static const int variant = [] { const char *e = getenv("DOA_SCAN_VARIANT"); return e ? atoi(e) : -1; }();
+            if (variant >= 0 && P == 1024 && pk.val && pk.store && pk.M == 1) {
+                static unsigned long long *d_stamps = nullptr;
+                if ((variant & 64) && !d_stamps) (void)hipMalloc(&d_stamps, sizeof(unsigned long long) * 2 * 65536);
+                bool ok = false;
+#define DOA_LAB_VAR(V_)                                                                                               \
+    if (variant == (V_)) {                                                                                            \
+        hipLaunchKernelGGL((music_scan_peak1_lab_kernel<4, 4, T, (V_)>), lgrid, block, 0, st, co, z, sp, n_items, pk.xaxis, \
+                           pk.val, pk.loc, d_stamps);                                                                 \
+        ok = true;                                                                                                    \
+    }
+                DOA_LAB_VAR(0) DOA_LAB_VAR(1) DOA_LAB_VAR(2) DOA_LAB_VAR(3) DOA_LAB_VAR(4) DOA_LAB_VAR(6) DOA_LAB_VAR(7)
+                DOA_LAB_VAR(8) DOA_LAB_VAR(9) DOA_LAB_VAR(11) DOA_LAB_VAR(15) DOA_LAB_VAR(16) DOA_LAB_VAR(23) DOA_LAB_VAR(32)
+                DOA_LAB_VAR(33) DOA_LAB_VAR(41) DOA_LAB_VAR(71) DOA_LAB_VAR(79)
+#undef DOA_LAB_VAR
+                if (ok) {
+                    if (variant & 64) {
+                        static int printed = 0;
+                        if (printed < 3 && hipStreamSynchronize(st) == hipSuccess) {
+                            const int nw = lb * waves_per_block;
+                            std::vector<unsigned long long> h(2 * (size_t)nw);
+                            (void)hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+                            std::vector<double> ghz;
+                            for (int w = 0; w < nw; w++) if (h[2 * w + 1]) ghz.push_back((double)h[2 * w] / ((double)h[2 * w + 1] * 10.0));
+                            std::sort(ghz.begin(), ghz.end());
+                            if (!ghz.empty()) fprintf(stderr, "[lab] scan kernel in-kernel clock: median %.3f GHz (min %.3f max %.3f) over %zu waves, n_items %d\n",
+                                                      ghz[ghz.size() / 2], ghz.front(), ghz.back(), ghz.size(), n_items);
+                            printed++;
+                        }
+                    }
+                    return true;
+                }
+            }
+        }
+#endif
         if (!pk.val) DOA_LEAN_CH(false, false);
         else if (!pk.store) {
             // angles only (sp is scratch for irregular rows)

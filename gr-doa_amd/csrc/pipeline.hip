@@ -32,6 +32,7 @@ struct doa_music_pipeline {
     doa::DevBuf d_in[2], d_res;
     doa::DevBuf d_work[2];          // K1's piece sums (overlapping windows), one per copy/compute lane
     doa::PinnedBuf h_stage;         // scheduler-sized calls: one page-locked staging buffer, one copy each way
+    int fail_chunk = -1;            // doa_music_pipeline_inject_failure: one-shot, host-pointer entry only (tests)
 };
 
 // K1 -> EVD -> scan (+ peak) for n items on `st`; coefficient records at item offset `coef_off` of the
@@ -202,15 +203,18 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
         const size_t span = (size_t)(noutput_items - 1) * nonoverlap + h->K;
         const size_t span_al = (span + 1) & ~(size_t)1;
         const size_t in_bytes = span_al * N * sizeof(float2);
-        if (in_bytes <= kSmallCallBytes) {
-            const size_t n = (size_t)noutput_items;
-            // sections of the result block [max | argmax | cov | spectrum], each on a 256-byte boundary (the scan kernels'
-            // 16-byte stores need aligned spectrum rows)
-            auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-            const size_t pk_b = n * M * sizeof(float);
-            const size_t cov_b = cov_out ? n * N * N * sizeof(float2) : 0, spec_b = spectrum_out ? n * P * sizeof(float) : 0;
-            const size_t off_am = up(pk_b), off_cov = off_am + up(pk_b), off_spec = off_cov + up(cov_b);
-            const size_t out_bytes = off_spec + spec_b;
+        const size_t n = (size_t)noutput_items;
+        // sections of the result block [max | argmax | cov | spectrum], each on a 256-byte boundary (the scan kernels'
+        // 16-byte stores need aligned spectrum rows)
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t pk_b = n * M * sizeof(float);
+        const size_t cov_b = cov_out ? n * N * N * sizeof(float2) : 0, spec_b = spectrum_out ? n * P * sizeof(float) : 0;
+        const size_t off_am = up(pk_b), off_cov = off_am + up(pk_b), off_spec = off_cov + up(cov_b);
+        const size_t out_bytes = off_spec + spec_b;
+        // (the gate looks at BOTH directions: a short-snapshot, long-spectrum call returns n * P * 4 bytes, and staging
+        // hundreds of MiB of spectra through the page-locked buffer -- plus a host memcpy each -- is what the chunked
+        // path below exists to avoid)
+        if (in_bytes <= kSmallCallBytes && out_bytes <= kSmallCallBytes) {
             const size_t res_min = (size_t)h->max_batch * M * 2 * sizeof(float);
             int rc = h->h_stage.reserve(in_bytes > out_bytes ? in_bytes : out_bytes);
             if (rc == DOA_OK) rc = h->d_in[0].reserve(in_bytes);
@@ -223,17 +227,27 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
                 memcpy(hs + (size_t)k * span_al * sizeof(float2), input_items[k], span * sizeof(float2));
                 d_ptrs[k] = h->d_in[0].as<float2>() + (size_t)k * span_al;
             }
-            DOA_HIP_TRY(hipMemcpyAsync(h->d_in[0].p, hs, in_bytes, hipMemcpyHostToDevice, st));
-            char *dr = h->d_res.as<char>();
-            float *d_mx = reinterpret_cast<float *>(dr), *d_am = reinterpret_cast<float *>(dr + off_am);
-            void *d_cov = cov_out ? (void *)(dr + off_cov) : h->d_cov.p;
-            void *d_spec = spectrum_out ? (void *)(dr + off_spec) : nullptr;            // NULL = angles only
-            rc = run_dev(h, noutput_items, d_ptrs, d_cov, d_spec, d_mx, d_am, 0, st, 0);
+            // From the upload on, every exit synchronises the stream first: a copy still reading the staging buffer
+            // would race the next call's memcpy into it.
+            auto staged = [&]() -> int {
+                DOA_HIP_TRY(hipMemcpyAsync(h->d_in[0].p, hs, in_bytes, hipMemcpyHostToDevice, st));
+                char *dr = h->d_res.as<char>();
+                float *d_mx = reinterpret_cast<float *>(dr), *d_am = reinterpret_cast<float *>(dr + off_am);
+                void *d_cov = cov_out ? (void *)(dr + off_cov) : h->d_cov.p;
+                void *d_spec = spectrum_out ? (void *)(dr + off_spec) : nullptr;            // NULL = angles only
+                const int rr = (h->fail_chunk == 0) ? (doa::set_error("music_pipeline_work: injected failure"), DOA_ERR_HIP)
+                                                    : run_dev(h, noutput_items, d_ptrs, d_cov, d_spec, d_mx, d_am, 0, st, 0);
+                if (rr < 0) return rr;
+                // (the staging buffer is free again: the upload was enqueued before the kernels on the same stream, and
+                // the download below is ordered behind them)
+                DOA_HIP_TRY(hipMemcpyAsync(hs, dr, out_bytes, hipMemcpyDeviceToHost, st));
+                return DOA_OK;
+            };
+            rc = staged();
+            h->fail_chunk = -1;
+            const hipError_t se = hipStreamSynchronize(st);
             if (rc < 0) return rc;
-            // (the staging buffer is free again: the upload was enqueued before the kernels on the same stream, and
-            // the download below is ordered behind them)
-            DOA_HIP_TRY(hipMemcpyAsync(hs, dr, out_bytes, hipMemcpyDeviceToHost, st));
-            DOA_HIP_TRY(hipStreamSynchronize(st));
+            if (se != hipSuccess) { doa::set_error("music_pipeline_work: %s", hipGetErrorString(se)); return DOA_ERR_HIP; }
             memcpy(max_out, hs, pk_b);
             memcpy(argmax_out, hs + off_am, pk_b);
             if (cov_out) memcpy(cov_out, hs + off_cov, cov_b);
@@ -256,11 +270,12 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
         rc = h->d_work[1].reserve(ws);                 // lane 0 uses the workspace create() sized for max_batch
     if (rc != DOA_OK) return rc;
     float *d_mx = h->d_res.as<float>(), *d_am = d_mx + (size_t)h->max_batch * M;
-    int lane = 0;
-    for (size_t s0 = 0; s0 < (size_t)noutput_items; s0 += chunk, lane ^= 1) {
-        const size_t n = ((size_t)noutput_items - s0 < chunk) ? (size_t)noutput_items - s0 : chunk;
+    int lane = 0, chunk_index = 0;
+    // One chunk: uploads, kernels, downloads, all on its lane's stream.  A failure anywhere in it ends the loop, and the
+    // loop's exit -- normal or not -- synchronises BOTH lanes: the other lane may still be copying to or from caller-owned
+    // host buffers, which must be quiet before this call returns.
+    auto enqueue_chunk = [&](size_t s0, size_t n, hipStream_t st) -> int {
         const size_t span = (n - 1) * nonoverlap + h->K;
-        hipStream_t st = h->hst[lane];
         const void *d_ptrs[DOA_MAX_ANT_ELE];
         for (int k = 0; k < N; k++) {
             float2 *dst = h->d_in[lane].as<float2>() + k * span_al;
@@ -268,10 +283,11 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
             DOA_HIP_TRY(hipMemcpyAsync(dst, src, span * sizeof(float2), hipMemcpyHostToDevice, st));
             d_ptrs[k] = dst;
         }
+        if (h->fail_chunk == chunk_index) { doa::set_error("music_pipeline_work: injected failure in chunk %d", chunk_index); return DOA_ERR_HIP; }
         float2 *cov = h->d_cov.as<float2>() + s0 * N * N;
         float *spec = spectrum_out ? h->d_spec.as<float>() + s0 * P : nullptr;         // NULL = angles only
-        rc = run_dev(h, (int)n, d_ptrs, cov, spec, d_mx + s0 * M, d_am + s0 * M, s0, st, lane);
-        if (rc < 0) break;
+        const int rr = run_dev(h, (int)n, d_ptrs, cov, spec, d_mx + s0 * M, d_am + s0 * M, s0, st, lane);
+        if (rr < 0) return rr;
         if (cov_out)
             DOA_HIP_TRY(hipMemcpyAsync(static_cast<float2 *>(cov_out) + s0 * N * N, cov, n * N * N * sizeof(float2),
                                        hipMemcpyDeviceToHost, st));
@@ -282,12 +298,37 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
                                    hipMemcpyDeviceToHost, st));
         DOA_HIP_TRY(hipMemcpyAsync(static_cast<float *>(argmax_out) + s0 * M, d_am + s0 * M, n * M * sizeof(float),
                                    hipMemcpyDeviceToHost, st));
+        return DOA_OK;
+    };
+    for (size_t s0 = 0; s0 < (size_t)noutput_items; s0 += chunk, lane ^= 1, chunk_index++) {
+        const size_t n = ((size_t)noutput_items - s0 < chunk) ? (size_t)noutput_items - s0 : chunk;
+        rc = enqueue_chunk(s0, n, h->hst[lane]);
+        if (rc < 0) break;
     }
+    h->fail_chunk = -1;
     for (auto st : h->hst) {
         const hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess && rc >= 0) { doa::set_error("music_pipeline_work: %s", hipGetErrorString(e)); rc = DOA_ERR_HIP; }
     }
     return rc < 0 ? rc : noutput_items;
+}
+
+int doa_music_pipeline_inject_failure(doa_music_pipeline_t *h, int chunk_index)
+{
+    doa::clear_error();
+    if (!h || chunk_index < -1) { doa::set_error("music_pipeline_inject_failure: bad arguments"); return DOA_ERR_INVALID_ARG; }
+    h->fail_chunk = chunk_index;
+    return DOA_OK;
+}
+
+int doa_music_pipeline_lanes_idle(doa_music_pipeline_t *h)
+{
+    doa::clear_error();
+    if (!h) { doa::set_error("music_pipeline_lanes_idle: bad arguments"); return DOA_ERR_INVALID_ARG; }
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
+    for (auto st : h->hst)
+        if (st && hipStreamQuery(st) != hipSuccess) return 0;
+    return 1;
 }
 
 }  // extern "C"

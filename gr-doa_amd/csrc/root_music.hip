@@ -50,6 +50,62 @@ __device__ __forceinline__ double fast_rcp(double x)
     return fma(y, e, y);
 }
 
+// Selection stage (reference lib/rootMUSIC_linear_array_impl.cc:122-145) on the GR lanes of one group, lane k holding
+// root k (is_root: k < 2N-2): dist = 1 - |z| (:122), keep dist > 0 -- strictly inside (:125-127) --, num_targets times the
+// interior root closest to the circle (index_min: ties -> the first, i.e. the lowest root index), angle =
+// 180 acos(arg z / (2 pi d)) / pi (:135), a used root becomes inf + 0i with dist inf (:138-139) -- so once the interior
+// roots are exhausted index_min lands on an inf entry, arg(inf + 0i) = 0 and the slot reads 90 degrees --, ascending
+// sort (:144; NaN last).  No interior root at all: the reference raises inside arma::index_min; here NaN angles and
+// status 1.  Shared by the solver kernel and by root_select_kernel (the selection on caller-supplied roots).
+template <int GR>
+__device__ __forceinline__ void root_select(double zr, double zi, bool is_root, int k, int base, int lane, int item,
+                                            bool real_item, int M, double two_pi_d, float *__restrict__ out,
+                                            int *__restrict__ status)
+{
+    // dist = 1 - |z|; keep dist > 0; the M smallest, one at a time (:122-141)
+    double dist = is_root ? 1.0 - sqrt(zr * zr + zi * zi) : -1.0;
+    if (!(dist > 0.0)) dist = -1.0;
+    const unsigned long long inside_mask = __ballot(dist > 0.0);
+    const int n_inside = __popcll((inside_mask >> base) & ((GR == 64) ? ~0ull : ((1ull << GR) - 1ull)));
+    float my_aoa = 0.f;
+    for (int j = 0; j < M; j++) {
+        // group arg-min of dist over the remaining interior roots (ties -> lowest lane)
+        double bd = (dist > 0.0) ? dist : 1e300;
+        int bk = (dist > 0.0) ? k : GR;
+#pragma unroll
+        for (int m = 1; m < GR; m <<= 1) {
+            const double od = __shfl(bd, lane ^ m, kWave);
+            const int ok = __shfl(bk, lane ^ m, kWave);
+            if (od < bd || (od == bd && ok < bk)) { bd = od; bk = ok; }
+        }
+        double ang = 0.0;                                   // exhausted: arg(inf + 0i) = 0 -> 90 degrees
+        if (bk < GR) {
+            const double br = __shfl(zr, base + bk, kWave), bi = __shfl(zi, base + bk, kWave);
+            ang = atan2(bi, br);
+            if (k == bk) dist = -1.0;
+        }
+        const float a = (float)(180.0 * acos(ang / two_pi_d) / M_PI);
+        if (k == j) my_aoa = a;
+    }
+    // ascending sort of the M picks held by lanes 0..M-1 (NaN sorts last)
+    const float key = (my_aoa != my_aoa) ? INFINITY : my_aoa;
+    int rank = 0;
+    for (int j = 0; j < M; j++) {
+        const float kj = __shfl(key, base + j, kWave);
+        rank += (kj < key || (kj == key && j < k)) ? 1 : 0;
+    }
+    if (real_item) {
+        float *o = out + (size_t)item * M;
+        if (n_inside == 0) {
+            if (k < M) o[k] = __builtin_nanf("");
+            if (k == 0 && status) status[item] = 1;
+        } else {
+            if (k < M) o[rank] = my_aoa;
+            if (k == 0 && status) status[item] = 0;
+        }
+    }
+}
+
 // DEG = compile-time polynomial degree when it is known to be below GR (N = 4: degree 6 on 8 lanes),
 // so that neither the Horner recurrence nor the root-pair loop spends steps on padding.
 template <int GR, int DEG = GR>
@@ -134,48 +190,7 @@ __global__ __launch_bounds__(64) void root_music_group_kernel(const double *__re
         if (!(csum < INFINITY)) { zr = __builtin_nan(""); zi = __builtin_nan(""); }
     }
     if (roots_out && real_item && is_root) roots_out[(size_t)item * D + k] = make_double2(zr, zi);    // diagnostics
-    // dist = 1 - |z|; keep dist > 0; the M smallest, one at a time (:122-141)
-    double dist = is_root ? 1.0 - sqrt(zr * zr + zi * zi) : -1.0;
-    if (!(dist > 0.0)) dist = -1.0;
-    const unsigned long long inside_mask = __ballot(dist > 0.0);
-    const int n_inside = __popcll((inside_mask >> base) & ((GR == 64) ? ~0ull : ((1ull << GR) - 1ull)));
-    float my_aoa = 0.f;
-    for (int j = 0; j < M; j++) {
-        // group arg-min of dist over the remaining interior roots (ties -> lowest lane)
-        double bd = (dist > 0.0) ? dist : 1e300;
-        int bk = (dist > 0.0) ? k : GR;
-#pragma unroll
-        for (int m = 1; m < GR; m <<= 1) {
-            const double od = __shfl(bd, lane ^ m, kWave);
-            const int ok = __shfl(bk, lane ^ m, kWave);
-            if (od < bd || (od == bd && ok < bk)) { bd = od; bk = ok; }
-        }
-        double ang = 0.0;                                   // exhausted: arg(inf + 0i) = 0 -> 90 degrees
-        if (bk < GR) {
-            const double br = __shfl(zr, base + bk, kWave), bi = __shfl(zi, base + bk, kWave);
-            ang = atan2(bi, br);
-            if (k == bk) dist = -1.0;
-        }
-        const float a = (float)(180.0 * acos(ang / two_pi_d) / M_PI);
-        if (k == j) my_aoa = a;
-    }
-    // ascending sort of the M picks held by lanes 0..M-1 (NaN sorts last)
-    const float key = (my_aoa != my_aoa) ? INFINITY : my_aoa;
-    int rank = 0;
-    for (int j = 0; j < M; j++) {
-        const float kj = __shfl(key, base + j, kWave);
-        rank += (kj < key || (kj == key && j < k)) ? 1 : 0;
-    }
-    if (real_item) {
-        float *o = out + (size_t)item * M;
-        if (n_inside == 0) {
-            if (k < M) o[k] = __builtin_nanf("");
-            if (k == 0 && status) status[item] = 1;
-        } else {
-            if (k < M) o[rank] = my_aoa;
-            if (k == 0 && status) status[item] = 0;
-        }
-    }
+    root_select<GR>(zr, zi, is_root, k, base, lane, item, real_item, M, two_pi_d, out, status);
 }
 
 template <int GR, int DEG = GR>
@@ -204,6 +219,45 @@ int launch_root_music(int N, int M, float norm_spacing, int n_items, const void 
     else if (D <= 8) launch_root_group<8>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st, d_roots);
     else if (D <= 16) launch_root_group<16>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st, d_roots);
     else launch_root_group<32>(N, M, n_items, d_coef, d_out, d_status, two_pi_d, st, d_roots);
+    DOA_HIP_TRY(hipGetLastError());
+    return DOA_OK;
+}
+
+// The selection stage alone, on caller-supplied roots (diagnostics: doa_rootMUSIC_linear_array_select_debug): the same
+// root_select<GR> instantiation the solver kernel of this array size ends in, fed from memory instead of from the
+// Aberth iteration, so every branch of the rule can be driven with hand-made root lists.
+template <int GR>
+__global__ __launch_bounds__(64) void root_select_kernel(const double2 *__restrict__ roots, float *__restrict__ out,
+                                                         int *__restrict__ status, int n_items, int N, int M, double two_pi_d)
+{
+    constexpr int IPW = kWave / GR;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int k = lane % GR, base = lane - k;
+    int item = blockIdx.x * IPW + lane / GR;
+    const bool real_item = item < n_items;
+    if (!real_item) item = n_items - 1;
+    const int D = 2 * N - 2;
+    const bool is_root = k < D;
+    double zr = 0.0, zi = 0.0;
+    if (is_root) { const double2 z = roots[(size_t)item * D + k]; zr = z.x; zi = z.y; }
+    root_select<GR>(zr, zi, is_root, k, base, lane, item, real_item, M, two_pi_d, out, status);
+}
+
+int launch_root_select(int N, int M, float norm_spacing, int n_items, const void *d_roots, void *d_out, void *d_status,
+                       hipStream_t st)
+{
+    if (n_items <= 0) return DOA_OK;
+    const double two_pi_d = 2 * M_PI * (double)norm_spacing;
+    const int D = 2 * N - 2;
+#define DOA_SELECT(GR_)                                                                                             \
+    hipLaunchKernelGGL((root_select_kernel<GR_>), dim3((n_items + kWave / GR_ - 1) / (kWave / GR_)), dim3(64), 0, st, \
+                       (const double2 *)d_roots, (float *)d_out, (int *)d_status, n_items, N, M, two_pi_d)
+    if (D <= 2) DOA_SELECT(2);
+    else if (D <= 4) DOA_SELECT(4);
+    else if (D <= 8) DOA_SELECT(8);
+    else if (D <= 16) DOA_SELECT(16);
+    else DOA_SELECT(32);
+#undef DOA_SELECT
     DOA_HIP_TRY(hipGetLastError());
     return DOA_OK;
 }
@@ -346,6 +400,33 @@ int doa_rootMUSIC_linear_array_debug(doa_rootMUSIC_linear_array_t *h, int noutpu
     if (rc != DOA_OK) return rc;
     DOA_HIP_TRY(hipMemcpyAsync(output_items0, h->d_out.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
     if (roots_out) DOA_HIP_TRY(hipMemcpyAsync(roots_out, h->d_roots.p, root_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (status_out)
+        DOA_HIP_TRY(hipMemcpyAsync(status_out, h->d_status.p, (size_t)noutput_items * sizeof(int), hipMemcpyDeviceToHost,
+                                   h->stream));
+    DOA_HIP_TRY(hipStreamSynchronize(h->stream));
+    return noutput_items;
+}
+
+int doa_rootMUSIC_linear_array_select_debug(doa_rootMUSIC_linear_array_t *h, int noutput_items, const void *roots_in,
+                                            void *output_items0, int *status_out)
+{
+    doa::clear_error();
+    if (!h || noutput_items <= 0 || !roots_in || !output_items0) {
+        doa::set_error("rootMUSIC_linear_array_select_debug: bad arguments");
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
+    const int D = 2 * h->N - 2;
+    const size_t out_bytes = (size_t)noutput_items * h->M * sizeof(float);
+    const size_t root_bytes = (size_t)noutput_items * D * sizeof(double2);
+    int rc = h->d_out.reserve(out_bytes);
+    if (rc == DOA_OK) rc = h->d_roots.reserve(root_bytes);
+    if (rc == DOA_OK) rc = h->d_status.reserve((size_t)noutput_items * sizeof(int));
+    if (rc != DOA_OK) return rc;
+    DOA_HIP_TRY(hipMemcpyAsync(h->d_roots.p, roots_in, root_bytes, hipMemcpyHostToDevice, h->stream));
+    rc = doa::launch_root_select(h->N, h->M, h->norm_spacing, noutput_items, h->d_roots.p, h->d_out.p, h->d_status.p, h->stream);
+    if (rc != DOA_OK) { (void)hipStreamSynchronize(h->stream); return rc; }
+    DOA_HIP_TRY(hipMemcpyAsync(output_items0, h->d_out.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
     if (status_out)
         DOA_HIP_TRY(hipMemcpyAsync(status_out, h->d_status.p, (size_t)noutput_items * sizeof(int), hipMemcpyDeviceToHost,
                                    h->stream));

@@ -84,6 +84,7 @@ SIGNATURES = {
     "doa_rootMUSIC_linear_array_destroy": (None, [_vp]),
     "doa_rootMUSIC_linear_array_work": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "doa_rootMUSIC_linear_array_debug": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "doa_rootMUSIC_linear_array_select_debug": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "doa_rootMUSIC_linear_array_work_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "doa_antenna_correction_create": (_vp, [C.c_int, C.c_char_p]),
     "doa_antenna_correction_create_gains": (_vp, [C.c_int, _vp]),
@@ -102,6 +103,8 @@ SIGNATURES = {
     "doa_music_pipeline_set_stages": (C.c_int, [_vp, C.c_int]),
     "doa_music_pipeline_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp, _vp]),
     "doa_music_pipeline_work": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp]),
+    "doa_music_pipeline_inject_failure": (C.c_int, [_vp, C.c_int]),
+    "doa_music_pipeline_lanes_idle": (C.c_int, [_vp]),
     "doa_compass_mean_create": (_vp, [C.c_int]),
     "doa_compass_mean_destroy": (None, [_vp]),
     "doa_compass_mean_work": (C.c_int, [_vp, C.c_int, _vp, _vp]),

@@ -308,6 +308,16 @@ class rootMUSIC_linear_array(_Block):
         check(lib.doa_rootMUSIC_linear_array_debug(self._h, n, _vp(a), _vp(ang), _vp(roots), _vp(status)))
         return ang, roots, status
 
+    def select_debug(self, roots: np.ndarray):
+        """The device's root-selection stage alone (reference lib/rootMUSIC_linear_array_impl.cc:122-145) on the given
+        roots [n, 2N-2] complex128 -> (angles [n, M] float32, status [n] int32; 1 = no interior root)."""
+        z = np.ascontiguousarray(roots, dtype=np.complex128).reshape(-1, 2 * self.num_ant_ele - 2)
+        n = z.shape[0]
+        ang = np.empty((n, self.num_targets), dtype=_F32)
+        status = np.empty(n, dtype=np.int32)
+        check(lib.doa_rootMUSIC_linear_array_select_debug(self._h, n, _vp(z), _vp(ang), _vp(status)))
+        return ang, status
+
 
 class calibrate_lin_array(_Block):
     """doa.calibrate_lin_array(norm_spacing, num_ant_ele, pilot_angle) — gr::sync_block, vlen N^2
@@ -382,6 +392,14 @@ class music_pipeline(_Block):
     def set_stages(self, cov=True, evd=True, scan=True) -> None:
         """Profiling aid: drop stages from later work_dev calls (their outputs keep the previous call's values)."""
         check(lib.doa_music_pipeline_set_stages(self._h, (1 if cov else 0) | (2 if evd else 0) | (4 if scan else 0)))
+
+    def inject_failure(self, chunk_index: int) -> None:
+        """Test aid: the next work() call fails in chunk `chunk_index` as if a HIP call had (one-shot; -1 disarms)."""
+        check(lib.doa_music_pipeline_inject_failure(self._h, int(chunk_index)))
+
+    def lanes_idle(self) -> bool:
+        """Test aid: True when neither copy/compute lane of the host-buffer entry has work pending."""
+        return bool(check(lib.doa_music_pipeline_lanes_idle(self._h)))
 
     def work_dev(self, noutput_items, d_input_ptrs, d_cov_ptr, d_spec_ptr, d_max_ptr, d_argmax_ptr, stream=None) -> int:
         return check(lib.doa_music_pipeline_work_dev(

@@ -187,6 +187,18 @@ DOA_HIP_API int doa_rootMUSIC_linear_array_work(doa_rootMUSIC_linear_array_t *h,
 DOA_HIP_API int doa_rootMUSIC_linear_array_debug(doa_rootMUSIC_linear_array_t *h, int noutput_items,
                                                  const void *input_items0, void *output_items0,
                                                  void *roots_out, int *status_out);
+/* Diagnostics, second half: ONLY the root-selection stage of work() (lib/rootMUSIC_linear_array_impl.cc:122-145), run
+ * on the device -- the very code the solver kernel ends in -- on CALLER-SUPPLIED roots (roots_in: noutput_items x
+ * (2*num_ant_ele-2) interleaved re, im doubles, host memory), so that every branch of the rule can be driven with
+ * hand-made root lists: fewer than num_targets roots strictly inside the unit circle (missing slots read 90 degrees,
+ * :131-141), roots exactly on the circle (excluded by dist > 0, :125), equal distances (index_min takes the first),
+ * no interior root at all (status 1 / NaN angles; the reference raises).  PARITY UNPINNED in two corners, both stated
+ * in DESIGN.md section 5: the reference tests a FLOAT dist = 1 - |z| of cgeev's float roots, here dist is formed in double from
+ * double roots (a root within 6e-8 of the circle is dropped there and kept here); NaN angles (|arg z| > 2 pi d) sort
+ * last here, arma::sort's treatment of NaN depends on the Armadillo version. */
+DOA_HIP_API int doa_rootMUSIC_linear_array_select_debug(doa_rootMUSIC_linear_array_t *h, int noutput_items,
+                                                        const void *roots_in, void *output_items0,
+                                                        int *status_out);
 DOA_HIP_API int doa_rootMUSIC_linear_array_work_dev(doa_rootMUSIC_linear_array_t *h,
                                                     int noutput_items, const void *d_input_items0,
                                                     void *d_output_items0, void *hip_stream);
@@ -278,6 +290,14 @@ DOA_HIP_API int doa_music_pipeline_set_stages(doa_music_pipeline_t *h, int stage
 DOA_HIP_API int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items,
                                         const void *const *input_items, void *cov_out,
                                         void *spectrum_out, void *max_out, void *argmax_out);
+/* Test aids for the error path of doa_music_pipeline_work (not for production use).  inject_failure: the NEXT
+ * doa_music_pipeline_work call on this handle behaves as if a HIP call had failed in chunk `chunk_index` (0 = the first
+ * ~32 MiB chunk, or the only one of a scheduler-sized call) after that chunk's uploads were enqueued; one-shot, -1
+ * disarms.  Whatever fails inside the call, it returns only after BOTH of the handle's copy/compute lanes have been
+ * synchronised, so no copy to or from the caller's host buffers is in flight afterwards; lanes_idle reports exactly that
+ * (1 = both lanes idle, 0 = work pending, < 0 = error). */
+DOA_HIP_API int doa_music_pipeline_inject_failure(doa_music_pipeline_t *h, int chunk_index);
+DOA_HIP_API int doa_music_pipeline_lanes_idle(doa_music_pipeline_t *h);
 
 /* ---------------------------------------------------------------------------------------------
  * compass_mean — blocks.vector_to_streams(float, num_streams) + the averaging of doa.compass

@@ -274,3 +274,20 @@ def test_oracle_f64_equals_octave_golden_model(N, d, thetas, K, ovl, snr):
         assert int(np.argmax(spec[i])) == int(np.argmax(want))
         doa_deg = np.sort(_octave_rmusic(S_x, float(np.float32(d)), N, M))
         assert np.abs(np.sort(ang[i]) - doa_deg).max() <= 2e-4       # output is float32 degrees
+
+
+def test_root_selection_padding_rule_of_the_reference():
+    """lib/rootMUSIC_linear_array_impl.cc:131-141 restated once on explicit root sets (an oracle self-check; the device's
+    selection stage is run against this rule on hand-made roots in tests/test_gpu_root_music.py): with fewer than
+    num_targets interior roots the remaining picks hit an "inf" entry, arg(inf + 0i) = 0, i.e. 90 degrees; with none,
+    index_min runs on an empty vector (an Armadillo error)."""
+    roots = np.array([0.5 * np.exp(1j * 1.0), 2.0 * np.exp(1j * 1.0), 1.5, 1.25 * np.exp(-0.3j)])
+    got = oracle.root_music_select(roots, 0.5, 3, "f64")
+    want = np.sort(np.array([np.degrees(np.arccos(1.0 / np.pi)), 90.0, 90.0], np.float32))
+    assert np.allclose(got, want, atol=1e-5)
+    with pytest.raises(ValueError):
+        oracle.root_music_select(np.array([1.5, 2.0 + 1j]), 0.5, 1, "f64")
+    # a root exactly on the circle is not "inside" (dist > 0, :125), in either precision of dist
+    for prec in ("f32", "f64"):
+        got = oracle.root_music_select(np.array([1.0 + 0j, 0.5j, 3.0]), 0.5, 1, prec)
+        assert np.allclose(got, [np.degrees(np.arccos(0.5))], atol=1e-4)

@@ -218,3 +218,52 @@ def test_angles_only_mode_equals_the_full_pipeline(name):
     except doa.DoaError:
         pass                                            # non-finite rows are reported after the results are in place
     assert np.array_equal(h0, out["full"][0], equal_nan=True) and np.array_equal(h1, out["full"][1], equal_nan=True)
+
+
+@pytest.mark.parametrize("fail_chunk,small", [(0, False), (1, False), (2, False), (0, True)])
+def test_host_entry_failure_leaves_no_copy_in_flight(fail_chunk, small):
+    """VERDICT r2 #7 / ADVICE r2: a failure inside doa_music_pipeline_work -- in any chunk of the two-lane chunk loop, or
+    in the staged scheduler-sized path -- must not return while the other lane (or the staging upload) is still copying
+    to or from the caller's host buffers.  doa_music_pipeline_inject_failure makes chunk `fail_chunk` fail after its
+    uploads were enqueued; the call must report DOA_ERR_HIP, both lanes must be idle on return, and the next call on the
+    same handle must succeed and match a call on a fresh handle bit for bit."""
+    N, K, P, d, M = 4, 1024, 1024, 0.5, 1
+    n = 24 if small else 2 * ((32 << 20) // (K * N * 8)) + 77            # three chunks over two lanes, or one staged call
+    x = doa.sim.make_streams(N, n * K, [64.0], d, snr_db=15.0, seed=11)
+    pipe = doa.music_pipeline(N, K, 0, 0, d, M, P, max_batch=n)
+    mx, am = np.full((n, M), -7.0, np.float32), np.full((n, M), -7.0, np.float32)
+    cov = np.zeros((n, N * N), np.complex64)
+    spec = np.zeros((n, P), np.float32)
+    pipe.inject_failure(fail_chunk)
+    with pytest.raises(doa.DoaError) as ei:
+        pipe.work(n, [x[k] for k in range(N)], mx, am, cov_out=cov, spectrum_out=spec)
+    assert ei.value.status == -3 and "injected failure" in str(ei.value)
+    assert pipe.lanes_idle()                                           # nothing pending: the caller may reuse its buffers
+    # the buffers really are the caller's again: scribble over the inputs, then run a clean call on fresh copies
+    x2 = x.copy()
+    x[:] = 0
+    mx2, am2 = np.empty((n, M), np.float32), np.empty((n, M), np.float32)
+    cov2, spec2 = np.empty((n, N * N), np.complex64), np.empty((n, P), np.float32)
+    assert pipe.work(n, [x2[k] for k in range(N)], mx2, am2, cov_out=cov2, spectrum_out=spec2) == n     # one-shot: disarmed
+    ref = doa.music_pipeline(N, K, 0, 0, d, M, P, max_batch=n)
+    mx3, am3 = np.empty((n, M), np.float32), np.empty((n, M), np.float32)
+    cov3, spec3 = np.empty((n, N * N), np.complex64), np.empty((n, P), np.float32)
+    assert ref.work(n, [x2[k] for k in range(N)], mx3, am3, cov_out=cov3, spectrum_out=spec3) == n
+    assert np.array_equal(mx2, mx3) and np.array_equal(am2, am3) and np.array_equal(cov2, cov3) and np.array_equal(spec2, spec3)
+    assert np.abs(am2 - 64.0).max() <= 1.0
+
+
+def test_host_entry_short_snapshot_long_spectrum_takes_the_chunked_path():
+    """the staged one-copy path is gated on BOTH directions; a short-K, long-P call whose spectra exceed the
+    gate must not grow the page-locked staging buffer to hundreds of MiB -- and either path gives the same bits."""
+    N, K, P, d, M = 4, 16, 4096, 0.5, 1
+    n = 1500                                                            # in: 96 KiB per stream, out: 24 MiB of spectra
+    x = doa.sim.make_streams(N, n * K, [100.0], d, snr_db=25.0, seed=3)
+    pipe = doa.music_pipeline(N, K, 0, 0, d, M, P, max_batch=n)
+    mx, am, spec = np.empty((n, M), np.float32), np.empty((n, M), np.float32), np.empty((n, P), np.float32)
+    assert pipe.work(n, [x[k] for k in range(N)], mx, am, spectrum_out=spec) == n
+    # small calls of the same stream (staged path: 64 items -> 1 MiB of spectra) give the same rows
+    m = 64
+    mx_s, am_s, spec_s = np.empty((m, M), np.float32), np.empty((m, M), np.float32), np.empty((m, P), np.float32)
+    assert pipe.work(m, [x[k][:m * K] for k in range(N)], mx_s, am_s, spectrum_out=spec_s) == m
+    assert np.array_equal(spec_s, spec[:m]) and np.array_equal(am_s, am[:m]) and np.array_equal(mx_s, mx[:m])

@@ -165,13 +165,81 @@ def test_root_music_no_interior_root_is_an_error_and_spares_the_good_rows():
             oracle.root_music(Rb[i:i + 1], c["d"], M, N, "f64")
 
 
-def test_root_selection_padding_rule_of_the_reference():
-    # fewer than num_targets interior roots (not reachable from a covariance item, see the note above): the rule the
-    # device code mirrors -- remaining picks hit an "inf" entry, arg(inf + 0i) = 0, i.e. 90 degrees -- stated once on
-    # explicit root sets so that a change of either side shows up
-    roots = np.array([0.5 * np.exp(1j * 1.0), 2.0 * np.exp(1j * 1.0), 1.5, 1.25 * np.exp(-0.3j)])
-    got = oracle.root_music_select(roots, 0.5, 3, "f64")
-    want = np.sort(np.array([np.degrees(np.arccos(1.0 / np.pi)), 90.0, 90.0], np.float32))
-    assert np.allclose(got, want, atol=1e-5)
-    with pytest.raises(ValueError):
-        oracle.root_music_select(np.array([1.5, 2.0 + 1j]), 0.5, 1, "f64")
+def _select_cases(N, M, d, rng):
+    """Hand-made root lists [n, 2N-2] that drive every branch of lib/rootMUSIC_linear_array_impl.cc:122-145."""
+    D = 2 * N - 2
+    ph = lambda k: np.exp(1j * rng.uniform(-2 * np.pi * d, 2 * np.pi * d, k))       # visible region: real angles
+    out = []
+    # (a) j = 0..D interior roots, the rest outside: j < M exercises the 90-degree padding, j = 0 the error status
+    for j in range(D + 1):
+        z = np.concatenate([rng.uniform(0.2, 0.98, j) * ph(j), rng.uniform(1.02, 3.0, D - j) * ph(D - j)])
+        out.append(rng.permutation(z))
+    # (b) roots EXACTLY on the circle (|z| == 1.0 whichever way the modulus is formed: 1, -1, j, -j) are excluded by
+    # dist > 0 (:125)
+    on = np.array([1.0, -1.0, 1j, -1j])
+    for j in range(min(D, 4) + 1):
+        k_in = min(M, D - j)
+        z = np.concatenate([on[:j], rng.uniform(0.3, 0.9, k_in) * ph(k_in), rng.uniform(1.1, 2.0, D - j - k_in) * ph(D - j - k_in)])
+        out.append(z)
+        out.append(z[::-1].copy())
+    # (c) equal distances: index_min takes the first such root in the list's order (:133); radii exact in binary
+    for r in (0.5, 0.75):
+        k = min(D, M + 2)
+        z = np.concatenate([r * np.array([1.0, 1j, -1.0, -1j, 1.0, 1j])[:k] * 1.0, rng.uniform(1.5, 2.5, D - k) * ph(D - k)])
+        out.append(z)
+        out.append(np.roll(z, 1))
+    # (d) angles outside the visible region (|arg z| > 2 pi d): acos(> 1) = NaN, sorted last
+    if d < 0.5:
+        z = np.concatenate([rng.uniform(0.5, 0.9, D - 1) * np.exp(1j * rng.uniform(2 * np.pi * d + 0.05, np.pi, D - 1)), [0.95 * np.exp(0.1j)]])
+        out.append(z)
+    # (e) non-finite roots are never "inside"
+    z = np.concatenate([[complex(np.nan, 0.0), complex(np.inf, 0.0)], rng.uniform(0.4, 0.9, D - 2) * ph(D - 2)])[:D]
+    out.append(z)
+    return np.stack([np.asarray(z, np.complex128) for z in out])
+
+
+@pytest.mark.parametrize("N,M,d", [(2, 1, 0.5), (3, 2, 0.5), (4, 1, 0.5), (4, 2, 0.44), (4, 3, 0.5), (5, 3, 0.3), (8, 4, 0.35),
+                                   (9, 8, 0.5), (16, 3, 0.5), (16, 15, 0.25)])
+def test_device_selection_stage_on_hand_made_roots(N, M, d):
+    """the device's selection code (root_select, the stage every solver kernel ends in) run through
+    doa_rootMUSIC_linear_array_select_debug on caller-supplied roots, against the oracle's restatement of
+    lib/rootMUSIC_linear_array_impl.cc:122-145, branch by branch: fewer than num_targets interior roots -> 90 degree
+    padding (:131-141), roots exactly on the circle excluded (dist > 0, :125), equal distances -> first in order
+    (index_min), angle outside the visible region -> NaN (sorted last), no interior root -> status 1 + NaN row (the
+    reference raises).  dist is formed in double on both sides (the device's convention)."""
+    rng = np.random.default_rng(1000 * N + M)
+    roots = _select_cases(N, M, d, rng)
+    blk = doa.rootMUSIC_linear_array(d, M, N)
+    ang, status = blk.select_debug(roots)
+    seen = {"padded": 0, "error": 0, "nan": 0, "on_circle": 0}
+    for i, z in enumerate(roots):
+        with np.errstate(invalid="ignore"):
+            n_in = int(np.sum(1.0 - np.abs(z) > 0.0))
+        seen["on_circle"] += int(np.any(np.abs(z) == 1.0))
+        if n_in == 0:
+            with pytest.raises(ValueError):
+                oracle.root_music_select(z, d, M, "f64")
+            assert status[i] == 1 and np.isnan(ang[i]).all(), (i, ang[i], status[i])
+            seen["error"] += 1
+            continue
+        want = oracle.root_music_select(z, d, M, "f64")
+        want = np.concatenate([np.sort(want[~np.isnan(want)]), want[np.isnan(want)]])      # NaN last (numpy sorts it last too)
+        assert status[i] == 0
+        assert np.array_equal(np.isnan(want), np.isnan(ang[i])), (i, want, ang[i])
+        ok = ~np.isnan(want)
+        assert np.all(np.abs(want[ok] - ang[i][ok]) <= 2e-5), (i, z, want, ang[i])
+        if n_in < M:
+            assert np.sum(ang[i] == 90.0) >= M - n_in, (i, ang[i])
+            seen["padded"] += 1
+        seen["nan"] += int(np.isnan(want).any())
+    assert seen["error"] >= 1 and seen["on_circle"] >= 2, seen
+    assert seen["padded"] >= (1 if M > 1 else 0), seen
+    # and the equal-distance rule depends on the ORDER of the list: rolling the list changes which root wins
+    if M == 1 and N >= 3:
+        z = np.zeros(2 * N - 2, np.complex128) + 2.0
+        z[0], z[1] = 0.5 * np.exp(0.3j), 0.5 * np.exp(-1.1j)
+        a0, _ = blk.select_debug(z[None, :])
+        z2 = z.copy(); z2[0], z2[1] = z[1], z[0]
+        a1, _ = blk.select_debug(z2[None, :])
+        w0, w1 = oracle.root_music_select(z, d, M, "f64"), oracle.root_music_select(z2, d, M, "f64")
+        assert abs(a0[0, 0] - w0[0]) <= 2e-5 and abs(a1[0, 0] - w1[0]) <= 2e-5 and abs(w0[0] - w1[0]) > 1.0
