@@ -14,12 +14,11 @@ covariance (K1), Hermitian EVD + noise projector (K2+K3), spectrum scan (K4), pe
 distinct input/output batches whose total footprint exceeds the 256 MiB Infinity Cache, so every
 step streams from HBM (a single 144 MiB working set would be served on-die).
 
-Steps alternate over a few HIP streams (default 4, one pipeline handle = one workspace per
-stream): each step's three launches stay in order on its own stream, while the HBM-bound covariance
-of one batch overlaps the latency-bound EVD / scan of the batches before it (the covariance kernel fills
-the register file of every SIMD, so the EVD / scan of step i really run beside the covariance of step
-i + 2: three or four streams keep that from stalling the covariance of step i + 2; same-box A/B runs put four ahead
-of three by 1-3 us per step more often than not).
+The K timed steps go through ONE pipeline handle in ONE call of doa_music_pipeline_work_dev_batches (K batches): the
+library spreads the batches over its own lanes (default 4 HIP streams + workspaces owned by the handle), so that the
+HBM-bound covariance of one batch overlaps the issue-bound EVD / scan of its neighbours; the call is made in its
+detached form and joined by doa_music_pipeline_synchronize, inside the timed region.  --mode streams is the round-1/2 arrangement for comparison: four handles on four
+caller-created streams, one work_dev call per step.
 
 Multi-GPU (weak scaling): snapshots are independent, so every rank owns its own batch and there is
 no data-path collective; value = (steps * batch * world) / max-over-ranks time.  Timing: barrier + synchronize, clock
@@ -271,46 +270,215 @@ def gr_model(lib, xs, n, chunk=16):
     return n / dt, [round(b / dt, 2) for b in busy]
 
 
-def sharded_check(doa, torch, dist, world, local_rank, per_rank=512, K=1024, ovl=256, theta=(41.0, 117.0)):
-    """doa.distributed.run_sharded over one simulated stream (two fixed sources, overlapping windows, FB averaging):
-    returns what rank 0 reports.  Correctness = every gathered angle pair sits on the two source directions."""
+def sharded_run(doa, torch, dist, world, rank, local_rank, per_rank=4096, K=1024, ovl=256, theta=(41.0, 117.0)):
+    """The product's sharded driver (doa.distributed.run_sharded) over ONE simulated stream of world x per_rank overlapping
+    windows (two fixed sources, forward-backward averaging), as a measurement: every rank generates only its own shard +
+    halo (seekable device generator), runs its pipeline, and the per-snapshot angle pairs meet in one all_gather --
+    generation, compute and gather timed separately (max over ranks).  With world > 1 the ingest-rank variant is timed too:
+    rank 0 holds the whole stream and doa.distributed.scatter_shards sends every other rank its shard, halo included
+    (configs[4]'s "RCCL scatter/gather over xGMI").  Correctness = every gathered pair sits on the two source directions
+    and the scattered shard equals the generated one bit for bit."""
     n_total, S = world * per_rank, K - ovl
     dev = torch.device("cuda", local_rank)
+    st = torch.cuda.current_stream()
+    local_error = []
+    t = {}
 
-    def my_samples(begin, end):                     # this rank's shard only, generated in place
+    def sync_time():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    def generate(begin, end):
         bufs = [torch.zeros(end - begin, dtype=torch.complex64, device=dev) for _ in range(N_ANT)]
         try:
             src = doa.sim_source(N_ANT, 0.45, list(theta), [0.031, 0.047], None, None, 0.1, seed=99)
             src.seek(begin)
-            src.work_dev(end - begin, [b.data_ptr() for b in bufs], torch.cuda.current_stream())
-            torch.cuda.synchronize()
+            src.work_dev(end - begin, [b.data_ptr() for b in bufs], st)
         except Exception as e:
             local_error.append(repr(e))
         return bufs
 
-    local_error = []
+    def my_samples(begin, end):
+        t0 = sync_time()
+        bufs = generate(begin, end)
+        t["generation_s"] = sync_time() - t0
+        t["kept"] = bufs
+        return bufs
+
+    pipe_box = {}
 
     def compute(bufs, n_local):
         # never raises: a rank that failed locally must still enter the all_gather its peers are waiting in
         am = torch.full((n_local, 2), float("nan"), dtype=torch.float32, device=dev)
         try:
-            pipe = doa.music_pipeline(N_ANT, K, ovl, 1, 0.45, 2, P_SPEC, max(n_local, 1))
+            pipe = pipe_box.setdefault("p", doa.music_pipeline(N_ANT, K, ovl, 1, 0.45, 2, P_SPEC, max(n_local, 1)))
             mx = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
-            pipe.work_dev(n_local, [b.data_ptr() for b in bufs], 0, 0, mx.data_ptr(), am.data_ptr(), torch.cuda.current_stream())
-            torch.cuda.synchronize()
+            args = (n_local, [b.data_ptr() for b in bufs], 0, 0, mx.data_ptr(), am.data_ptr(), st)
+            pipe.work_dev(*args)                          # first call: lazy workspaces
+            t0 = sync_time()
+            pipe.work_dev(*args)
+            t["compute_s"] = sync_time() - t0
         except Exception as e:
             local_error.append(repr(e))
         return am
 
-    t0 = time.perf_counter()
-    angles, shard = doa.distributed.run_sharded(my_samples, n_total, K, ovl, compute, dist=dist)
-    dt = time.perf_counter() - t0
+    local, shard = doa.distributed.run_sharded(my_samples, n_total, K, ovl, compute, dist=dist, gather=False)
+    shards = doa.sharding.all_shards(n_total, world, K, ovl)
+    doa.distributed.gather_results(local, shards, dist)                 # first gather: communicator set-up
+    t0 = sync_time()
+    angles = doa.distributed.gather_results(local, shards, dist)
+    t["gather_s"] = sync_time() - t0
     a = angles.cpu().numpy()
     err = float(max(abs(a[:, 0] - max(theta)).max(), abs(a[:, 1] - min(theta)).max()))     # port 1 is sorted descending
-    return {"snapshots": n_total, "ranks": world, "halo_samples": ovl, "shard_samples_rank0": shard.n_samples,
-            "gathered_rows": int(a.shape[0]), "max_angle_error_deg": err, "ok": bool(a.shape[0] == n_total and err <= 1.0),
-            **({"rank0_error": local_error[0]} if local_error else {}),
-            "seconds_incl_generation": dt}
+    red = lambda v: doa.distributed.max_over_ranks(float(v), device="cuda", dist=dist)
+    out = {"snapshots": n_total, "snapshots_per_rank": per_rank, "ranks": world, "halo_samples": ovl,
+           "shard_samples_rank0": shard.n_samples if rank == 0 else None,
+           "gathered_rows": int(a.shape[0]), "max_angle_error_deg": err, "ok": bool(a.shape[0] == n_total and err <= 1.0),
+           "generation_s": red(t.get("generation_s", float("nan"))), "compute_s": red(t.get("compute_s", float("nan"))),
+           "gather_s": red(t.get("gather_s", float("nan"))),
+           "gather_bytes_per_rank": int(per_rank * 2 * 4)}
+    out["compute_snapshots_per_s"] = n_total / out["compute_s"] if out["compute_s"] == out["compute_s"] else None
+    if world > 1:
+        # ingest-rank variant: rank 0 generates the WHOLE stream, the shards travel (input side of configs[4])
+        try:
+            whole = generate(0, (n_total - 1) * S + K) if rank == 0 else None
+            doa.distributed.scatter_shards(whole, N_ANT, n_total, K, ovl, src=0, device=dev, dist=dist)      # set-up pass
+            t0 = sync_time()
+            mine = doa.distributed.scatter_shards(whole, N_ANT, n_total, K, ovl, src=0, device=dev, dist=dist)
+            t_sc = red(sync_time() - t0)
+            same = all(bool(torch.equal(torch.view_as_real(m), torch.view_as_real(k))) for m, k in zip(mine, t["kept"]))
+            sent = sum(sh.n_samples for sh in shards[1:]) * N_ANT * 8
+            out["scatter"] = {"seconds": t_sc, "bytes_sent_by_rank0": int(sent), "GBs": sent / t_sc / 1e9,
+                              "shards_equal_generated": bool(same)}
+            del whole, mine
+        except Exception as e:
+            out["scatter"] = {"error": repr(e)}
+    if local_error:
+        out["rank0_error"] = local_error[0]
+    return out
+
+
+def other_configs(doa, torch, st, lanes=4, check=True):
+    """Driver-timed figures for the other BASELINE.json configs (parity-test cases, never the headline): configs[2] (Root-MUSIC,
+    N=4, 2 sources), configs[3] (N=16, 3 sources, P=4096, MFMA covariance) and the simulation flowgraph's shape (K=2048,
+    overlap 512, forward-backward, 2 sources).  Each: us per 4096-snapshot step serial (one stream) and overlapped (the
+    handle's lanes; for Root-MUSIC, which has no fused entry, caller streams), items/s; preceded -- outside any timing -- by a
+    16-row spot check against the oracle (the checker leg of this script, like cpu_baseline: fp64 restatement of the
+    reference's formulas on the same samples)."""
+    import numpy as np
+    B = 4096
+    out = {}
+
+    def timed(fn, reps):
+        fn(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(reps)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    def spot(name, streams, N, K, ovl, fb, d, M, P, cov_t, am_t, root_t):
+        if not check:
+            return None
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import doa_oracle as oracle
+        n = 16
+        span = (n - 1) * (K - ovl) + K
+        x = np.stack([t[:span].cpu().numpy() for t in streams])
+        R64 = oracle.autocorrelate(x, K, ovl, fb, n, precision="f64")
+        Rg = cov_t[:n].cpu().numpy()
+        res = {"rows": n, "cov_rel_err": float(np.abs(Rg - R64).max() / np.abs(R64).max())}
+        ok = res["cov_rel_err"] <= 2e-6
+        if am_t is not None:
+            s64 = oracle.music_lin_array(Rg, d, M, N, P, "f64")
+            _, loc = oracle.find_local_max(s64.astype(np.float32), M, P, 0.0, 180.0)
+            res["peak_location_max_diff_deg"] = float(np.abs(am_t[:n].cpu().numpy() - loc).max())
+            ok = ok and res["peak_location_max_diff_deg"] <= 180.0 / P + 1e-3
+        if root_t is not None:
+            a64 = oracle.root_music(Rg, d, M, N, "f64")
+            res["root_angle_max_diff_deg"] = float(np.abs(root_t[:n].cpu().numpy() - a64).max())
+            ok = ok and res["root_angle_max_diff_deg"] <= 1e-3
+        res["ok"] = bool(ok)
+        return res
+
+    def pipeline_config(name, N, K, ovl, fb, d, M, P, nbuf, reps, desc):
+        S = K - ovl
+        span = (B - 1) * S + K
+        bufs = []
+        for b in range(nbuf):
+            if ovl == 0:
+                s, _ = doa.sim.make_batch_streams_torch(N, K, B, d, M, SNR_DB, seed=500 + b, device="cuda")
+            else:           # one continuous stream with overlapping windows: the simulation flowgraph's own generator
+                s = [torch.empty(span, dtype=torch.complex64, device="cuda") for _ in range(N)]
+                s = doa.sim.stream_slab_torch(s)
+                src = doa.sim_source(N, d, [30.0, 123.0][:M], [0.03125, 0.0625][:M], None, None, 0.1, seed=600 + b)
+                src.work_dev(span, [t.data_ptr() for t in s], st)
+            bufs.append(s)
+        ptrs = [[t.data_ptr() for t in s] for s in bufs]
+        cov = [torch.empty((B, N * N), dtype=torch.complex64, device="cuda") for _ in range(nbuf)]
+        spec = [torch.empty((B, P), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+        mx = [torch.empty((B, M), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+        am = [torch.empty((B, M), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+        pipe = doa.music_pipeline(N, K, ovl, fb, d, M, P, B)
+        pipe.set_lanes(lanes)
+        serial = lambda n: [pipe.work_dev(B, ptrs[i % nbuf], cov[i % nbuf].data_ptr(), spec[i % nbuf].data_ptr(), mx[i % nbuf].data_ptr(),
+                                          am[i % nbuf].data_ptr(), st) for i in range(n)]
+        def lanes_fn(n):
+            idx = [i % nbuf for i in range(n)]
+            pipe.work_dev_batches(B, [ptrs[b] for b in idx], [cov[b].data_ptr() for b in idx], [spec[b].data_ptr() for b in idx],
+                                  [mx[b].data_ptr() for b in idx], [am[b].data_ptr() for b in idx], doa.DETACHED)
+            pipe.synchronize()
+        serial(1)
+        torch.cuda.synchronize()
+        chk = spot(name, bufs[0], N, K, ovl, fb, d, M, P, cov[0], am[0], None)
+        us_serial = timed(serial, reps)
+        us_lanes = timed(lanes_fn, reps) if nbuf % lanes == 0 or nbuf >= lanes else None
+        out[name] = {"config": desc, "batch": B, "us_per_step_serial": us_serial, "us_per_step_overlapped": us_lanes,
+                     "items_per_s_serial": B / us_serial * 1e6, "items_per_s_overlapped": (B / us_lanes * 1e6) if us_lanes else None,
+                     "overlap": f"doa_music_pipeline_work_dev_batches (detached), {lanes} lanes", "spot_check": chk}
+
+    # configs[2]: covariance + Root-MUSIC (no fused entry: two blocks on one stream; overlapped = 4 caller streams)
+    try:
+        N, K, d, M = 4, 1024, 0.44, 2
+        nbuf = 4
+        bufs = [doa.sim.make_batch_streams_torch(N, K, B, d, M, SNR_DB, seed=400 + b, device="cuda")[0] for b in range(nbuf)]
+        ptrs = [[t.data_ptr() for t in s] for s in bufs]
+        cov = [torch.empty((B, N * N), dtype=torch.complex64, device="cuda") for _ in range(nbuf)]
+        ang = [torch.empty((B, M), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+        covb = [doa.autocorrelate(N, K, 0, 0) for _ in range(lanes)]
+        rootb = [doa.rootMUSIC_linear_array(d, M, N) for _ in range(lanes)]
+        sts = [torch.cuda.Stream() for _ in range(lanes)]
+        def serial(n):
+            for i in range(n):
+                b = i % nbuf
+                covb[0].work_dev(B, ptrs[b], cov[b].data_ptr(), st)
+                rootb[0].work_dev(B, cov[b].data_ptr(), ang[b].data_ptr(), st)
+        def overl(n):
+            for i in range(n):
+                b, k = i % nbuf, i % lanes
+                covb[k].work_dev(B, ptrs[b], cov[b].data_ptr(), sts[k])
+                rootb[k].work_dev(B, cov[b].data_ptr(), ang[b].data_ptr(), sts[k])
+        serial(1)
+        torch.cuda.synchronize()
+        chk = spot("cfg3", bufs[0], N, K, 0, 0, d, M, 0, cov[0], None, ang[0])
+        us_s, us_o = timed(serial, 20), timed(overl, 20)
+        out["cfg3_root_music"] = {"config": "BASELINE.json configs[2]: N=4, 2 sources, d=0.44, K=1024, covariance + Root-MUSIC", "batch": B,
+                                  "us_per_step_serial": us_s, "us_per_step_overlapped": us_o, "items_per_s_serial": B / us_s * 1e6,
+                                  "items_per_s_overlapped": B / us_o * 1e6, "overlap": f"{lanes} caller streams, one handle pair each",
+                                  "spot_check": chk}
+        del bufs, cov, ang
+    except Exception as e:
+        out["cfg3_root_music"] = {"error": repr(e)}
+    for args_ in (("flowgraph_shape", 4, 2048, 512, 1, 0.4, 2, 1024, 4, 20,
+                   "run_MUSIC_lin_array_simulation.grc's shape: N=4, 2 sources, d=0.4, K=2048, overlap 512, forward-backward, P=1024"),
+                  ("cfg4_n16", 16, 1024, 0, 0, 0.5, 3, 4096, 4, 8,
+                   "BASELINE.json configs[3]: N=16, 3 sources, K=1024, P=4096 (MFMA covariance, subspace EVD, LDS-row scan)")):
+        try:
+            pipeline_config(*args_)
+        except Exception as e:
+            out[args_[0]] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    return out
 
 
 def load_launcher():
@@ -330,7 +498,11 @@ def main():
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
                     help="internal precision of EVD + scan (items are fp32 either way)")
     ap.add_argument("--nbuf", type=int, default=6, help="distinct batches rotated through (defeats L3 residency)")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the steps alternate over")
+    ap.add_argument("--streams", type=int, default=4, help="lanes of the pipeline handle (--mode batches) / caller streams (--mode streams)")
+    ap.add_argument("--mode", choices=("batches", "streams"), default="batches",
+                    help="batches: the K steps as ONE doa_music_pipeline_work_dev_batches call on one handle (the library owns the "
+                         "overlap); streams: one work_dev call per step on caller-created streams, one handle each (rounds 1-2)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the driver-timed secondary configs (cfg3, cfg4, flowgraph shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scan-roofline", action="store_true",
                     help="skip the isolated scan-kernel measurements (keeps rocprof kernel averages clean)")
@@ -374,14 +546,21 @@ def main():
                   file=sys.stderr)
     doa.set_internal_precision(args.precision)
     n_streams = max(1, args.streams)
-    pipes = [doa.music_pipeline(N_ANT, K_SNAP, 0, 0, NORM_SPACING, M_SRC, P_SPEC, BATCH) for _ in range(n_streams)]
+    batched = (args.mode == "batches")
+    # --mode batches: ONE handle, its lanes are the streams; --mode streams: one handle per caller stream
+    pipes = [doa.music_pipeline(N_ANT, K_SNAP, 0, 0, NORM_SPACING, M_SRC, P_SPEC, BATCH) for _ in range(1 if batched else n_streams)]
+    if batched:
+        pipes[0].set_lanes(n_streams)
     hip_streams = [torch.cuda.Stream() for _ in range(n_streams)]
     cov_blk = doa.autocorrelate(N_ANT, K_SNAP, 0, 0)
     music_blk = doa.MUSIC_lin_array(NORM_SPACING, M_SRC, N_ANT, P_SPEC)
     peak_blk = doa.find_local_max(M_SRC, P_SPEC, 0.0, 180.0)
 
     # ---- synthetic, device-resident inputs (setup, not timed) -------------------------------------
-    nbuf = max(n_streams + 1, args.nbuf)       # a buffer set is never reused while its step may be in flight
+    # a multiple of the lane count: step i and step i + nbuf (same buffers) then run on the SAME lane / stream, i.e. in
+    # order -- no two steps ever write one buffer set concurrently
+    nbuf = max(n_streams + 1, args.nbuf)
+    nbuf = ((nbuf + n_streams - 1) // n_streams) * n_streams
     streams, thetas = [], []
     for b in range(nbuf):
         s, th = doa.sim.make_batch_streams_torch(N_ANT, K_SNAP, BATCH, NORM_SPACING, M_SRC, SNR_DB,
@@ -395,10 +574,29 @@ def main():
     am = [torch.empty((BATCH, M_SRC), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
     st = torch.cuda.current_stream()
 
-    def step(i):
+    def step(i):                                      # --mode streams: one work_dev call per step on a caller stream
         b, k = i % nbuf, i % n_streams
         pipes[k].work_dev(BATCH, in_ptrs[b], cov[b].data_ptr(), spec[b].data_ptr(), mx[b].data_ptr(),
                           am[b].data_ptr(), hip_streams[k])
+
+    def run_steps(first, count, with_spectrum=True):
+        """`count` steps starting at step index `first` (buffer set = step index mod nbuf)."""
+        if not batched:
+            for i in range(first, first + count):
+                if with_spectrum:
+                    step(i)
+                else:
+                    b, k = i % nbuf, i % n_streams
+                    pipes[k].work_dev(BATCH, in_ptrs[b], cov[b].data_ptr(), 0, mx[b].data_ptr(), am[b].data_ptr(), hip_streams[k])
+            return
+        # detached: the inputs are resident and complete (synchronize before the region), the join is the handle's own
+        # host-side synchronize below -- no cross-stream event inside the timed region (they cost ~150 us per fork + join on
+        # this runtime, DESIGN.md section 4)
+        idx = [i % nbuf for i in range(first, first + count)]
+        pipes[0].work_dev_batches(BATCH, [in_ptrs[b] for b in idx], [cov[b].data_ptr() for b in idx],
+                                  [spec[b].data_ptr() for b in idx] if with_spectrum else None,
+                                  [mx[b].data_ptr() for b in idx], [am[b].data_ptr() for b in idx], doa.DETACHED)
+        pipes[0].synchronize()
 
     def barrier():
         torch.cuda.synchronize()
@@ -406,21 +604,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # setup, not warm-up: touch every pipeline handle / stream / buffer set once, so that first-launch code
-    # loading and lazy workspace allocation never fall into a short timed region whatever --warmup says
-    for i in range(max(n_streams, nbuf)):
-        step(i)
+    # setup, not warm-up: touch every lane / stream / buffer set once, so that first-launch code loading and lazy
+    # workspace allocation never fall into a short timed region whatever --warmup says
+    run_steps(0, max(n_streams, nbuf))
     torch.cuda.synchronize()
-    for i in range(args.warmup):
-        step(i)
+    if args.warmup > 0:
+        run_steps(0, args.warmup)
     # Timed region: barrier + synchronize on both sides.  Each rank stops its clock when ITS K steps have completed
     # (synchronize), the closing barrier follows, and the job's time is the MAX over ranks -- the time from the common
     # start to the slowest rank's completion, without the closing collective's own latency (tens of microseconds of
     # RCCL launch + ring on 8 GPUs would otherwise be charged to a 20-step region of ~0.6 ms).
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run_steps(0, args.steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -429,30 +625,22 @@ def main():
 
     # Secondary figure, never `value`: the same steps with no spectrum pointer (the fused block with only its angle port
     # connected: the 4 KiB row per snapshot is neither converted to dB nor written).
-    def step_angles(i):
-        b, k = i % nbuf, i % n_streams
-        pipes[k].work_dev(BATCH, in_ptrs[b], cov[b].data_ptr(), 0, mx[b].data_ptr(), am[b].data_ptr(), hip_streams[k])
-    for i in range(8):
-        step_angles(i)
+    run_steps(0, 8, with_spectrum=False)
     torch.cuda.synchronize()
     ta = time.perf_counter()
-    for i in range(args.steps):
-        step_angles(i)
+    run_steps(0, args.steps, with_spectrum=False)
     torch.cuda.synchronize()
     angles_elapsed = time.perf_counter() - ta
-    for i in range(n_streams):                        # leave full results (spectra included) in the buffers the checks read
-        step(args.steps - 1 - i)
+    run_steps(max(0, args.steps - n_streams), min(n_streams, args.steps))    # leave full results (spectra included) behind
     torch.cuda.synchronize()
 
     # Not part of the timed region (snapshots are independent: the path has no data-path collective): the sharded
-    # run itself, product code (doa.distributed.run_sharded) -- ONE stream of world x 512 overlapping windows is cut
-    # into contiguous per-rank shards with their overlap halo, every rank generates only its own samples (seekable
-    # device generator), runs its pipeline, and the per-snapshot angles meet in one RCCL all_gather.
+    # run itself, product code (doa.distributed.run_sharded), as a measurement of its own (sharded_run's docstring).
     sharded = None
     if dist is not None:
         torch.cuda.synchronize()
         try:
-            sharded = sharded_check(doa, torch, dist, world, local_rank)
+            sharded = sharded_run(doa, torch, dist, world, rank, local_rank)
         except Exception as e:                      # never lose the throughput number to the check
             sharded = {"error": repr(e)}
 
@@ -513,6 +701,8 @@ def main():
                                "batch=4096 snapshots/step, complex fp32, SNR 20 dB",
                    "batch": BATCH, "inputs": N_ANT, "snapshot_size": K_SNAP, "pspectrum_len": P_SPEC,
                    "num_targets": M_SRC, "internal_precision": args.precision, "rotating_batches": nbuf, "hip_streams": n_streams,
+                   "step_entry": ("doa_music_pipeline_work_dev_batches (detached) + doa_music_pipeline_synchronize: the K steps in one call on one handle, %d library-owned lanes" % n_streams)
+                                 if batched else "doa_music_pipeline_work_dev per step on %d caller streams, one handle each" % n_streams,
                    "input_layout": "N separate stream buffers in HBM, doa_stream_stride_bytes apart (4.5 KiB modulo 8 KiB: no HBM-channel aliasing between streams)",
                    "parallelism": f"snapshot-sharded x{world}, no data-path collective"},
         "pipeline_gbs": ab["fused_total"] * value / world / 1e9,      # fused algorithmic bytes x rate, per GPU
@@ -545,6 +735,11 @@ def main():
             except Exception as e:                      # secondary figure: never lose the headline to it
                 rs[key] = {"error": repr(e)}
         out["roofline_scan"] = rs
+    if world == 1 and args.precision == 64 and not args.no_other_configs:
+        try:
+            out["other_configs"] = other_configs(doa, torch, st, lanes=n_streams, check=not args.no_cpu_baseline)
+        except Exception as e:
+            out["other_configs"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:
         # in a child process: the CPU leg must never be able to take the GPU number down with it
         import subprocess

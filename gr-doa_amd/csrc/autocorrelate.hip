@@ -406,7 +406,7 @@ static int cov_waves_per_cu(int n_ch)
 {
     // N <= 4: one wave per snapshot at the benchmark batch; wider arrays hold 2-4x the registers per wave and measured
     // better with 8 (N = 6: 54.4 vs 57.3 us, 4-stream step 56.8 vs 63.0 us)
-    static int v = [] { const char *e = getenv("DOA_COV_WAVES_PER_CU"); return e ? atoi(e) : -1; }();
+    const int v = DOA_LAB_ENV_INT("DOA_COV_WAVES_PER_CU", -1);
     return v >= 0 ? v : (n_ch <= 4 ? 16 : 8);
 }
 
@@ -442,10 +442,8 @@ template <int TN> static void launch_wave(const CovArgs &g, bool vec2, hipStream
         hipLaunchKernelGGL((cov_wave_kernel<TN, false, 1, false>), grid, block, 0, st, g);
         return;
     }
-    // read-once stream: non-temporal loads (+19 % on MI355X); DOA_COV_NT=0 restores the default policy
-    static const int nt = [] { const char *e = getenv("DOA_COV_NT"); return e ? atoi(e) : 1; }();
-    if (nt) hipLaunchKernelGGL((cov_wave_kernel<TN, true, UN, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((cov_wave_kernel<TN, true, UN, false>), grid, block, 0, st, g);
+    // read-once stream: non-temporal loads (+19 % on MI355X against the default cache policy)
+    hipLaunchKernelGGL((cov_wave_kernel<TN, true, UN, true>), grid, block, 0, st, g);
 }
 
 // Launches K1 on `st`.  d_in: N device pointers.  Returns DOA_OK / error.
@@ -453,9 +451,8 @@ template <int TN> static void launch_wave(const CovArgs &g, bool vec2, hipStream
 // take the read-once path)
 size_t autocorrelate_workspace_bytes(int N, int K, int ovl, int n_out)
 {
-    static const int on = [] { const char *e = getenv("DOA_COV_PIECES"); return e ? atoi(e) : 1; }();
     const int S = K - ovl;
-    if (!on || ovl <= 0 || N > 8 || n_out <= 0 || (S & 1) || ((K % S) & 1)) return 0;
+    if (ovl <= 0 || N > 8 || n_out <= 0 || (S & 1) || ((K % S) & 1)) return 0;
     return (size_t)(n_out + K / S) * 2 * N * N * sizeof(float2);
 }
 

@@ -101,4 +101,12 @@ int doa_calibrate_lin_array_work(doa_calibrate_lin_array_t *h, int noutput_items
     return noutput_items;
 }
 
+int doa_calibrate_lin_array_set_internal_precision(doa_calibrate_lin_array_t *h, int bits)
+{
+    doa::clear_error();
+    if (!h || (bits != 32 && bits != 64)) { doa::set_error("calibrate_lin_array_set_internal_precision: need a handle and bits = 32 or 64"); return DOA_ERR_INVALID_ARG; }
+    h->bits = bits;
+    return DOA_OK;
+}
+
 }  // extern "C"

@@ -17,6 +17,8 @@ void set_error(const char *fmt, ...)
 }
 void clear_error() { g_err[0] = '\0'; }
 
+void prime_hw_queues(int dev);
+
 int ensure_device(int *device_out)
 {
     int n = 0;
@@ -30,7 +32,30 @@ int ensure_device(int *device_out)
     int dev = 0;
     DOA_HIP_TRY(hipGetDevice(&dev));
     if (device_out) *device_out = dev;
+    prime_hw_queues(dev);
     return DOA_OK;
+}
+
+// The HIP runtime creates its hardware queues lazily, one per newly USED stream until its pool (4 by default) is full, and
+// maps later streams onto the existing ones.  Streams that caused a queue to be created overlap their kernels measurably
+// worse than streams mapped onto a populated pool: four pipeline chains on the first four streams of a process run at
+// 32.6-32.9 us per 4096-snapshot step, on any later four at 26.0-26.8 (tools/lab/lanes_sweep.py with PRE_STREAMS = 0 / 3+,
+// same box, whoever creates the streams).  So the pool is populated once per device, before any handle creates a stream:
+// four throw-away streams, one trivial operation each; they stay alive for the life of the process (64 bytes of device memory).
+void prime_hw_queues(int dev)
+{
+    static std::atomic<unsigned> primed{0};
+    if (dev < 0 || dev >= 32) return;
+    const unsigned bit = 1u << dev;
+    if (primed.fetch_or(bit) & bit) return;
+    void *scratch = nullptr;
+    if (hipMalloc(&scratch, 64) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (int i = 0; i < 4; i++) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        (void)hipMemsetAsync(scratch, 0, 64, s);
+        (void)hipStreamSynchronize(s);
+    }
 }
 
 int cu_count()

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -28,7 +29,8 @@ void clear_error();
         }                                                                                       \
     } while (0)
 
-// Binds the calling thread to a usable HIP device (the current one); DOA_ERR_NO_DEVICE if none.
+// Binds the calling thread to a usable HIP device (the current one); DOA_ERR_NO_DEVICE if none.  First call per device: populates
+// the runtime's hardware-queue pool (prime_hw_queues, common.hip).
 int ensure_device(int *device_out);
 // Makes `device` (the one the handle was created on) current for the calling thread if it is not.
 int bind_device(int device);
@@ -52,6 +54,14 @@ struct PinnedBuf {
 };
 
 int internal_precision_bits();  // 32 or 64 (doa_set_internal_precision)
+
+// Launch-shape knobs for same-box A/B runs exist only in lab builds (make LAB=1); the default build has none of them
+// compiled in and this is the constant `dflt`.
+#ifdef DOA_LAB
+#define DOA_LAB_ENV_INT(name, dflt) ([] { static const int v_ = [] { const char *e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }(); return v_; }())
+#else
+#define DOA_LAB_ENV_INT(name, dflt) (dflt)
+#endif
 
 // Distance between the device copies of consecutive input streams (doa_stream_stride_bytes): the stream size rounded up
 // to 8 KiB plus 4.5 KiB, so that stream k starts 4.5 k KiB further into the 8 KiB period than stream 0 -- sixteen
@@ -122,14 +132,25 @@ __device__ __forceinline__ float wave_allreduce_max(float v)
     v = fmaxf(v, dpp_move<0x143, 0xC>(v, v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// (six v_min_f32 with the DPP control on the instruction itself: written with update_dpp + fminf the compiler issues a move,
+// a canonicalising max and the min per step.  v_min_f32 returns the other operand for a NaN one, like fminf.  A DPP read of
+// a VGPR the previous VALU instruction wrote needs two wait states, which nothing inserts inside inline asm.)
 __device__ __forceinline__ float wave_allreduce_min(float v)
 {
-    v = fminf(v, dpp_move<0xB1, 0xF>(v, v));
-    v = fminf(v, dpp_move<0x4E, 0xF>(v, v));
-    v = fminf(v, dpp_move<0x124, 0xF>(v, v));
-    v = fminf(v, dpp_move<0x128, 0xF>(v, v));
-    v = fminf(v, dpp_move<0x142, 0xA>(v, v));
-    v = fminf(v, dpp_move<0x143, 0xC>(v, v));
+    asm volatile("s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 

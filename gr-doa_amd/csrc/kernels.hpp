@@ -26,8 +26,15 @@ inline int coef_stride(int N) { return 2 * N; }
 
 // K2+K3: batched Hermitian EVD + noise projector + diagonal sums.  d_coef (float records, for the
 // scan), d_coef_d (double records, same layout, for the root finder) and d_pn may each be NULL.
+// d_cheb (optional; N <= 4, evd_bits == 64): a second record per item, 8 doubles, holding the null spectrum's polynomial
+// in the form the lean scan kernel evaluates, Q = A(c) + s B(c): [a0, a1, a2, a3, b0, b1, b2, 0] (music_scan_impl.hpp,
+// ChebQ) -- the change of basis is per item, so it belongs to the kernel that runs once per item.
 int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
-                     int evd_bits, hipStream_t st);
+                     int evd_bits, hipStream_t st, void *d_cheb = nullptr);
+inline bool music_uses_cheb(int N, int bits) { return N <= 4 && bits == 64; }
+constexpr int kChebRecord = 8;      // doubles per item
+// diagnostics: items that left the signal-subspace fast path of K2+K3 for the Jacobi fall-back since the last reset
+long long evd_fallback_count(bool reset);
 // calibrate_lin_array (calibrate.hip): d_pilot = N float2 (pilot steering vector), d_out = n_items*N float2
 int launch_calibrate(int N, int n_items, const void *d_R, const void *d_pilot, void *d_out, int bits, hipStream_t st);
 // K4: spectrum scan in float (bits == 32, float coefficient records) or double (bits == 64, double
@@ -37,7 +44,8 @@ int launch_calibrate(int N, int n_items, const void *d_R, const void *d_pilot, v
 struct PeakTables;
 int launch_music_scan(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec, void *d_q,
                       hipStream_t st, const PeakTables *peaks = nullptr, void *d_max = nullptr,
-                      void *d_argmax = nullptr, bool *peaks_done = nullptr, bool store_spectrum = true);
+                      void *d_argmax = nullptr, bool *peaks_done = nullptr, bool store_spectrum = true,
+                      const void *d_cheb = nullptr);
 
 // K5 (find_local_max.hip)
 struct PeakTables {

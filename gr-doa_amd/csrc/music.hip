@@ -65,11 +65,12 @@ DOA_SCAN_SIZES(DOA_SCAN_EXTERN)
 
 int launch_music_scan(const MusicTables &t, int bits, int n_items, const void *d_coef, void *d_spec, void *d_q,
                       hipStream_t st, const PeakTables *peaks, void *d_max, void *d_argmax, bool *peaks_done,
-                      bool store_spectrum)
+                      bool store_spectrum, const void *d_cheb)
 {
     if (peaks_done) *peaks_done = false;
     if (n_items <= 0) return DOA_OK;
     ScanPeakArgs pk;
+    pk.cheb = (bits == 64) ? d_cheb : nullptr;
     if (peaks && d_max && d_argmax && peaks->L == t.P) {
         pk.xaxis = peaks->d_x.as<float>(); pk.val = (float *)d_max; pk.loc = (float *)d_argmax; pk.M = peaks->M;
         pk.store = store_spectrum;
@@ -105,7 +106,7 @@ struct doa_MUSIC_lin_array {
     int device = 0;
     long long items_total = 0;
     hipStream_t stream = nullptr;
-    doa::DevBuf d_in, d_out, d_coef, d_pn, d_q;
+    doa::DevBuf d_in, d_out, d_coef, d_pn, d_q, d_cheb;
 };
 
 static int music_validate(const char *who, float norm_spacing, int num_targets, int num_ant_ele)
@@ -157,7 +158,7 @@ void doa_MUSIC_lin_array_destroy(doa_MUSIC_lin_array_t *h)
 {
     if (!h) return;
     h->tab.release();
-    h->d_in.release(); h->d_out.release(); h->d_coef.release(); h->d_pn.release(); h->d_q.release();
+    h->d_in.release(); h->d_out.release(); h->d_coef.release(); h->d_pn.release(); h->d_q.release(); h->d_cheb.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -177,12 +178,15 @@ int doa_MUSIC_lin_array_work_dev(doa_MUSIC_lin_array_t *h, int noutput_items, co
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const int N = h->tab.N;
     int rc = h->d_coef.reserve((size_t)noutput_items * doa::coef_stride(N) * sizeof(double));
+    const bool cheb = doa::music_uses_cheb(N, h->bits);
+    if (rc == DOA_OK && cheb) rc = h->d_cheb.reserve((size_t)noutput_items * doa::kChebRecord * sizeof(double));
     if (rc != DOA_OK) return rc;
     const bool dbl = (h->bits == 64);
     rc = doa::launch_music_evd(N, h->tab.M, noutput_items, d_input_items0, dbl ? nullptr : h->d_coef.p,
-                               dbl ? h->d_coef.p : nullptr, nullptr, h->bits, st);
+                               dbl ? h->d_coef.p : nullptr, nullptr, h->bits, st, cheb ? h->d_cheb.p : nullptr);
     if (rc != DOA_OK) return rc;
-    rc = doa::launch_music_scan(h->tab, h->bits, noutput_items, h->d_coef.p, d_output_items0, nullptr, st);
+    rc = doa::launch_music_scan(h->tab, h->bits, noutput_items, h->d_coef.p, d_output_items0, nullptr, st, nullptr, nullptr, nullptr,
+                                nullptr, true, cheb ? h->d_cheb.p : nullptr);
     if (rc != DOA_OK) return rc;
     h->items_total += noutput_items;
     return noutput_items;
@@ -243,6 +247,22 @@ int doa_MUSIC_lin_array_debug(doa_MUSIC_lin_array_t *h, int noutput_items, const
         DOA_HIP_TRY(hipMemcpyAsync(null_spectrum_out, h->d_q.p, sp_bytes, hipMemcpyDeviceToHost, h->stream));
     DOA_HIP_TRY(hipStreamSynchronize(h->stream));
     return noutput_items;
+}
+
+long long doa_hip_evd_fallback_count(int reset)
+{
+    doa::clear_error();
+    int dev = 0;
+    if (doa::ensure_device(&dev) != DOA_OK) return -1;
+    return doa::evd_fallback_count(reset != 0);
+}
+
+int doa_MUSIC_lin_array_set_internal_precision(doa_MUSIC_lin_array_t *h, int bits)
+{
+    doa::clear_error();
+    if (!h || (bits != 32 && bits != 64)) { doa::set_error("MUSIC_lin_array_set_internal_precision: need a handle and bits = 32 or 64"); return DOA_ERR_INVALID_ARG; }
+    h->bits = bits;
+    return DOA_OK;
 }
 
 }  // extern "C"

@@ -19,7 +19,7 @@ namespace doa {
 template <int N, typename T>
 __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
                                                        double *__restrict__ coef_d, float2 *__restrict__ pn_out,
-                                                       int n_items, int M)
+                                                       int n_items, int M, double *__restrict__ cheb_d)
 {
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= n_items) return;
@@ -34,6 +34,18 @@ __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict_
     if (coef_d) {
 #pragma unroll
         for (int k = 0; k < 2 * N; k++) coef_d[(size_t)item * (2 * N) + k] = (double)u[k];
+    }
+    if (cheb_d) {
+        // Q(psi) = u0 + 2 sum_l (x_l cos(l psi) - y_l sin(l psi)), u_l = x_l + j y_l, in powers of c = cos psi and s = sin psi
+        // (cos 2x = 2c^2 - 1, cos 3x = 4c^3 - 3c, sin 2x = 2sc, sin 3x = s(4c^2 - 1)):  Q = A(c) + s B(c),
+        // A = (u0 - 2x2) + (2x1 - 6x3) c + 4x2 c^2 + 8x3 c^3,  B = (2y3 - 2y1) - 4y2 c - 8y3 c^2   (music_scan_impl.hpp: ChebQ)
+        const double u0 = (double)u[0];
+        const double x1 = (N > 1) ? (double)u[1] : 0.0, y1 = (N > 1) ? (double)u[2] : 0.0;
+        const double x2 = (N > 2) ? (double)u[3] : 0.0, y2 = (N > 2) ? (double)u[4] : 0.0;
+        const double x3 = (N > 3) ? (double)u[5] : 0.0, y3 = (N > 3) ? (double)u[6] : 0.0;
+        double *o = cheb_d + (size_t)item * kChebRecord;
+        o[0] = u0 - 2 * x2; o[1] = 2 * x1 - 6 * x3; o[2] = 4 * x2; o[3] = 8 * x3;
+        o[4] = 2 * y3 - 2 * y1; o[5] = -4 * y2; o[6] = -8 * y3; o[7] = 0.0;
     }
 }
 
@@ -383,20 +395,19 @@ __device__ __forceinline__ unsigned caterpillar_mask(unsigned m)
 // lanes, so the kernel's register allocation is that of the sweeps (the row-per-lane epilogue alone
 // needs ~200 VGPRs in double, which would halve the resident waves).  !LEAN: diagnostics (P_N) and
 // calibrate mode through the shared row-per-lane epilogue.
+// One item on one wave (the body of music_evd_block16_kernel; also the fall-back of the subspace-iteration kernel below).
+// sVr / sVi / sLam: 16 x 16 + 16 values of LDS owned by this wave.
 template <typename T, bool LEAN>
-__global__ __launch_bounds__(64) void music_evd_block16_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
-                                                               double *__restrict__ coef_d, float2 *__restrict__ pn_out,
-                                                               int n_items, int N, int M,
-                                                               const float2 *__restrict__ pilot, float2 *__restrict__ cal_out)
+__device__ __forceinline__ void evd_block16_item(const float2 *__restrict__ Ri, int item, float *__restrict__ coef,
+                                                 double *__restrict__ coef_d, float2 *__restrict__ pn_out, int N, int M,
+                                                 const float2 *__restrict__ pilot, float2 *__restrict__ cal_out,
+                                                 T *__restrict__ sVr, T *__restrict__ sVi, T *__restrict__ sLam)
 {
     constexpr int G = 16;
-    __shared__ T sVr[G * G], sVi[G * G], sLam[G];
     const int lane = threadIdx.x & (kWave - 1);
     // lane = 16 (a >> 1) + 2 b + (a & 1): the two block rows that share a 16-lane DPP row are interleaved, so that
     // "column block b -> b +- 1" is a DPP row shift by 2 lanes whose out-of-row lanes are exactly b = 0 / b = 7
     const int a = ((lane >> 4) << 1) | (lane & 1), b = (lane & 15) >> 1;
-    const int item = blockIdx.x;                         // grid = n_items
-    const float2 *Ri = R + (size_t)item * (N * N);
     T xr[2][2], xi[2][2], vr[2][2], vi[2][2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -576,6 +587,82 @@ __global__ __launch_bounds__(64) void music_evd_block16_kernel(const float2 *__r
     }
 }
 
+template <typename T, bool LEAN>
+__global__ __launch_bounds__(64) void music_evd_block16_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
+                                                               double *__restrict__ coef_d, float2 *__restrict__ pn_out,
+                                                               int n_items, int N, int M,
+                                                               const float2 *__restrict__ pilot, float2 *__restrict__ cal_out)
+{
+    __shared__ T sVr[16 * 16], sVi[16 * 16], sLam[16];
+    const int item = blockIdx.x;                         // grid = n_items
+    evd_block16_item<T, LEAN>(R + (size_t)item * (N * N), item, coef, coef_d, pn_out, N, M, pilot, cal_out, sVr, sVi, sLam);
+}
+
+}  // namespace doa
+#include "evd_subspace.hpp"
+namespace doa {
+
+// One wave per item: the signal-subspace iteration (evd_subspace.hpp) first; whatever it does not certify takes the
+// block Jacobi above on the same wave.  G = 8 (N <= 8) / 16, MC = num_targets (1..4); double only.
+template <int G, int MC, bool PN>
+__global__ __launch_bounds__(64) void music_evd_subspace_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
+                                                                double *__restrict__ coef_d, float2 *__restrict__ pn_out,
+                                                                int n_items, int N, int *__restrict__ fallback_count)
+{
+    __shared__ double sVr[16 * 16], sVi[16 * 16], sLam[16];
+    const int item = blockIdx.x;                         // grid = n_items
+    const float2 *Ri = R + (size_t)item * (N * N);
+    if (evd_subspace_item<G, MC, PN>(Ri, item, coef, coef_d, pn_out, N, sVr, sVi)) return;
+    if (fallback_count && (threadIdx.x & (kWave - 1)) == 0) atomicAdd(fallback_count, 1);
+    if constexpr (PN) evd_block16_item<double, false>(Ri, item, coef, coef_d, pn_out, N, MC, nullptr, nullptr, sVr, sVi, sLam);
+    else evd_block16_item<double, true>(Ri, item, coef, coef_d, nullptr, N, MC, nullptr, nullptr, sVr, sVi, sLam);
+}
+
+template <int G, int MC>
+static void launch_evd_subspace_gm(int N, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn, hipStream_t st,
+                                   int *d_fallback_count)
+{
+    if (d_pn)
+        hipLaunchKernelGGL((music_evd_subspace_kernel<G, MC, true>), dim3(n_items), dim3(64), 0, st, (const float2 *)d_R,
+                           (float *)d_coef, (double *)d_coef_d, (float2 *)d_pn, n_items, N, d_fallback_count);
+    else
+        hipLaunchKernelGGL((music_evd_subspace_kernel<G, MC, false>), dim3(n_items), dim3(64), 0, st, (const float2 *)d_R,
+                           (float *)d_coef, (double *)d_coef_d, nullptr, n_items, N, d_fallback_count);
+}
+// Diagnostics: items of subspace-kernel launches that took the Jacobi fall-back (one device counter per process, on the
+// device that was current at first use; doa_hip_evd_fallback_count reads and optionally clears it).
+static int *evd_fallback_counter()
+{
+    static int *p = [] {
+        int *q = nullptr;
+        if (hipMalloc(&q, sizeof(int)) != hipSuccess) return (int *)nullptr;
+        if (hipMemset(q, 0, sizeof(int)) != hipSuccess) { (void)hipFree(q); return (int *)nullptr; }
+        return q;
+    }();
+    return p;
+}
+long long evd_fallback_count(bool reset)
+{
+    int *p = evd_fallback_counter();
+    if (!p) return -1;
+    int v = 0;
+    if (hipMemcpy(&v, p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;       // (synchronises with the device)
+    if (reset) (void)hipMemset(p, 0, sizeof(int));
+    return v;
+}
+
+// 4 < N <= 16, 1 <= M <= 4, 2 M <= N (the iteration pays when the signal subspace is the small one)
+static bool launch_evd_subspace(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
+                                hipStream_t st, int *d_fallback_count = nullptr)
+{
+    if (N <= 4 || N > 16 || M < 1 || M > 4 || 2 * M > N) return false;
+#define DOA_SUB(G_, M_) launch_evd_subspace_gm<G_, M_>(N, n_items, d_R, d_coef, d_coef_d, d_pn, st, d_fallback_count)
+    if (N <= 8) { if (M == 1) DOA_SUB(8, 1); else if (M == 2) DOA_SUB(8, 2); else if (M == 3) DOA_SUB(8, 3); else DOA_SUB(8, 4); }
+    else { if (M == 1) DOA_SUB(16, 1); else if (M == 2) DOA_SUB(16, 2); else if (M == 3) DOA_SUB(16, 3); else DOA_SUB(16, 4); }
+#undef DOA_SUB
+    return true;
+}
+
 template <typename T>
 static void launch_evd_block16(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
                                hipStream_t st, const void *d_pilot = nullptr, void *d_cal = nullptr)
@@ -612,19 +699,19 @@ int launch_calibrate(int N, int n_items, const void *d_R, const void *d_pilot, v
 }
 
 template <int N> static void launch_evd_n(int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
-                                          int bits, hipStream_t st)
+                                          int bits, hipStream_t st, void *d_cheb)
 {
     dim3 block(64), grid((n_items + 63) / 64);
     if (bits == 32)
         hipLaunchKernelGGL((music_evd_kernel<N, float>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,
-                           (double *)d_coef_d, (float2 *)d_pn, n_items, M);
+                           (double *)d_coef_d, (float2 *)d_pn, n_items, M, (double *)nullptr);
     else
         hipLaunchKernelGGL((music_evd_kernel<N, double>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,
-                           (double *)d_coef_d, (float2 *)d_pn, n_items, M);
+                           (double *)d_coef_d, (float2 *)d_pn, n_items, M, (double *)d_cheb);
 }
 
 int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
-                     int evd_bits, hipStream_t st)
+                     int evd_bits, hipStream_t st, void *d_cheb)
 {
     if (n_items <= 0) return DOA_OK;
     if (N < 2 || N > DOA_MAX_ANT_ELE) {
@@ -633,28 +720,25 @@ int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, v
     }
     // N <= 4: one lane per item, everything in registers (measured 10.5 us vs 11.0 us for the
     // 4-lane group kernel at batch 4096: at this size the cross-lane traffic eats the shorter
-    // dependency chain).  N > 4: 8 or 16 lanes per item (15x / 17x faster than one lane per item with
-    // the matrices in scratch).  DOA_EVD_KERNEL=1 forces the group kernel for N <= 4 (A/B runs).
-    static const int force_group = [] { const char *e = getenv("DOA_EVD_KERNEL"); return e ? atoi(e) : 0; }();
+    // dependency chain).  N > 4: 8 lanes per item (N <= 8) or one wave per item (block Jacobi), 15x / 17x faster than
+    // one lane per item with the matrices in scratch.
     const bool f32 = (evd_bits == 32);
-    static const int block16 = [] { const char *e = getenv("DOA_EVD16_BLOCK"); return e ? atoi(e) : 1; }();
-    if (N > 8 && block16) {
+    // wide arrays, few sources, double: signal-subspace iteration with the block Jacobi as its per-item fall-back
+    if (!f32 && launch_evd_subspace(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st, evd_fallback_counter())) {
+        DOA_HIP_TRY(hipGetLastError());
+        return DOA_OK;
+    }
+    if (N > 8) {
         if (f32) launch_evd_block16<float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
         else launch_evd_block16<double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
-    } else if (N > 8) {
-        if (f32) launch_evd_group<16, float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
-        else launch_evd_group<16, double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
     } else if (N > 4) {
         if (f32) launch_evd_group<8, float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
         else launch_evd_group<8, double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
-    } else if (force_group == 1) {
-        if (f32) launch_evd_group<4, float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
-        else launch_evd_group<4, double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
     } else {
         switch (N) {
-        case 2: launch_evd_n<2>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
-        case 3: launch_evd_n<3>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
-        default: launch_evd_n<4>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st); break;
+        case 2: launch_evd_n<2>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st, d_cheb); break;
+        case 3: launch_evd_n<3>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st, d_cheb); break;
+        default: launch_evd_n<4>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st, d_cheb); break;
         }
     }
     DOA_HIP_TRY(hipGetLastError());

@@ -6,11 +6,12 @@
 
 namespace doa {
 
-struct ScanPeakArgs {           // optional fused K5
+struct ScanPeakArgs {           // optional fused K5, and the lean kernel's record pointer
     const float *xaxis = nullptr;
     float *val = nullptr, *loc = nullptr;
     int M = 0;
     bool store = true;          // false: nobody wants the spectrum (angles-only pipeline call); d_spec is scratch then
+    const void *cheb = nullptr; // N <= 4, double: the pre-transformed records of launch_music_evd (kChebRecord doubles per item)
 };
 
 // returns true when the fused peak pick ran (fast paths only)

@@ -259,6 +259,9 @@ template <int N, typename T> struct ChebQ {
         a0 = u0 - 2 * x2; a1 = 2 * x1 - 6 * x3; a2 = 4 * x2; a3 = 8 * x3;
         b0 = 2 * y3 - 2 * y1; b1 = -4 * y2; b2 = -8 * y3;
     }
+    // from the record the EVD kernel already wrote in this basis (launch_music_evd, d_cheb): [a0 a1 a2 a3 b0 b1 b2 0]
+    struct Pre {};
+    __device__ __forceinline__ ChebQ(Pre, const T (&r)[8]) : a0(r[0]), a1(r[1]), a2(r[2]), a3(r[3]), b0(r[4]), b1(r[5]), b2(r[6]) {}
     __device__ __forceinline__ T operator()(T cs, T sn) const
     {
         const T A = fma(fma(fma(a3, cs, a2), cs, a1), cs, a0);
@@ -268,22 +271,48 @@ template <int N, typename T> struct ChebQ {
 };
 
 // The benchmark shape of K4+K5, lean: P == 256*CH exactly (no bounds predicates), compiled polynomial size ==
-// the array size, coefficients wave-uniform.  lean_scan_item is one item of it.  Nothing generic is compiled in, which keeps it at ~110 VGPRs (4 waves per SIMD) where
+// the array size, coefficients wave-uniform.  lean_scan_item is one item of it.  Nothing generic is compiled in, which keeps it at ~100 VGPRs (4 waves per SIMD) where
 // the general kernel needs 200+:
-//   * pass 1 keeps Q itself and its wave minimum (no reciprocal per angle);
-//   * pass 2 is dB = -10 log10(2) log2(Q (1/Qmin)): ONE transcendental per angle; the angles that can tie with the
-//     maximum take LeanNorm::db's exact path;
-//   * num_max_vals == 1: find_local_max's answer is the first angle holding the maximum; the tie compare lands
-//     in an SGPR pair, so the position search (s_ff1, s_min) is scalar work beside the vector pipe;
+//   * records: for N <= 4 in double the EVD kernel has already written the polynomial in the basis this kernel evaluates
+//     (launch_music_evd's d_cheb, 8 doubles per item): the change of basis is per-item work and used to be redone by every
+//     wave here (14 FP64 instructions and 10 VGPRs per item); otherwise the u_l record itself;
+//   * pass 1 keeps Q itself, the minimum of every 4-angle group of a lane, and the wave minimum (no reciprocal per angle);
+//   * pass 2 is dB = -10 log10(2) log2(Q (1/Qmin)): ONE transcendental per angle;
+//   * the tie rule (LeanNorm) costs ONE compare per lane and 256-angle chunk on ordinary rows: a lane can hold a tied angle
+//     in a chunk only if that chunk's lane minimum is <= q_hi; the per-angle compare / select (exactly 0 dB on the tied
+//     angles) and the scalar position search (s_ff1, s_min: find_local_max's answer for num_max_vals = 1 is the first angle
+//     holding the maximum) run only in chunks where some lane reports one -- one chunk of four on ordinary rows.  Every
+//     non-tied angle is strictly negative by construction (LeanNorm::inv_up), so skipping the select elsewhere changes no bit;
 //   * num_max_vals > 1 (MULTI, the flowgraph's two sources): the dB values stay in registers and go through the
 //     general peak_pick.
 // Items whose minimum of Q is not a normal positive float (zero, negative or non-finite null spectrum:
 // non-finite input, in practice) take a slow rolled path that follows the general kernel's semantics literally.
+template <int N, typename T> struct LeanRecord {
+    static constexpr bool kPre = (N <= 4 && sizeof(T) == 8);       // Chebyshev-form records from the EVD kernel
+    static constexpr int kLen = kPre ? kChebRecord : 2 * N;
+};
+// Q at table entry (cs, sn) from a record of either form
+template <int N, typename T> struct LeanQ {
+    static constexpr int RL = LeanRecord<N, T>::kLen;
+    const T (&c)[RL];
+    __device__ __forceinline__ explicit LeanQ(const T (&c_)[RL]) : c(c_) {}
+    __device__ __forceinline__ T operator()(T cs, T sn) const
+    {
+        if constexpr (LeanRecord<N, T>::kPre) {
+            const T A = fma(fma(fma(c[3], cs, c[2]), cs, c[1]), cs, c[0]);
+            const T B = fma(fma(c[6], cs, c[5]), cs, c[4]);
+            return fma(sn, B, A);
+        } else {
+            return null_spectrum<N, T>(c, cs, sn);
+        }
+    }
+};
+
 template <int N, int CH, typename T, bool MULTI, bool PEAKS>
-__device__ __forceinline__ void lean_scan_item_irregular(const T (&c)[2 * N], float (&qf)[CH][4], const T *__restrict__ ztab,
-                                                      float *__restrict__ row, const float *__restrict__ xs,
-                                                      float *__restrict__ pk_val_item, float *__restrict__ pk_loc_item,
-                                                      int M, int lane);
+__device__ __forceinline__ void lean_scan_item_irregular(const LeanQ<N, T> &Q, const T *__restrict__ ztab,
+                                                         float *__restrict__ row, const float *__restrict__ xs,
+                                                         float *__restrict__ pk_val_item, float *__restrict__ pk_loc_item,
+                                                         int M, int lane);
 
 // PEAKS = false: spectrum only (the stand-alone MUSIC_lin_array block: same arithmetic, hence the same bits, as the
 // pipeline's kernel); a template parameter rather than nullable pointers, which cost the hot path 30 VGPRs.
@@ -291,34 +320,34 @@ __device__ __forceinline__ void lean_scan_item_irregular(const T (&c)[2 * N], fl
 // its angle port connected), so the row is neither converted to dB (num_max_vals == 1: the answer is the first angle
 // whose rounded reciprocal ties with the maximum, and its value is 0 dB by construction) nor written; rows on the
 // irregular path use `row` as scratch.
-template <int N, int CH, typename T, bool MULTI, bool PEAKS = true, bool STORE = true>
-__device__ __forceinline__ void lean_scan_item(const T (&c)[2 * N], const T (&zr)[CH][4], const T (&zi)[CH][4],
+// ABL (lab builds only, make LAB=1): 1 = everything but the row stores, 2 = the row stores only (results invalid) -- the
+// two ablations behind the "what bounds this kernel" numbers in DESIGN.md
+template <int N, int CH, typename T, bool MULTI, bool PEAKS = true, bool STORE = true, int ABL = 0>
+__device__ __forceinline__ void lean_scan_item(const T (&c)[LeanRecord<N, T>::kLen], const T (&zr)[CH][4], const T (&zi)[CH][4],
                                                const T *__restrict__ ztab, float *__restrict__ row,
                                                const float *__restrict__ xs, float *__restrict__ pk_val_item,
                                                float *__restrict__ pk_loc_item, int M, int lane)
 {
     constexpr int P = 256 * CH;
-    // pass 1: the null spectrum itself (no reciprocal) and its minimum over the item
-    float qf[CH][4];
-    float mn = INFINITY;
-    if constexpr (N <= 4 && sizeof(T) == 8) {
-        const ChebQ<N, T> Q(c);
+    const LeanQ<N, T> Q(c);
+    if constexpr (ABL == 2) {
 #pragma unroll
         for (int j = 0; j < CH; j++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                qf[j][e] = (float)Q(zr[j][e], zi[j][e]);
-                mn = fminf(mn, qf[j][e]);
-            }
-    } else {
-#pragma unroll
-        for (int j = 0; j < CH; j++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                qf[j][e] = (float)null_spectrum<N, T>(c, zr[j][e], zi[j][e]);
-                mn = fminf(mn, qf[j][e]);
-            }
+            store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4((float)c[0], (float)j, -1.f, -2.f));
+        if (lane == 0) { pk_val_item[0] = 0.0f; pk_loc_item[0] = xs[lane]; }
+        return;
     }
+    // pass 1: the null spectrum itself (no reciprocal), the minimum of each lane's 4-angle groups, the item minimum
+    float qf[CH][4], cm[CH];
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) qf[j][e] = (float)Q(zr[j][e], zi[j][e]);
+        cm[j] = fminf(fminf(qf[j][0], qf[j][1]), fminf(qf[j][2], qf[j][3]));
+    }
+    float mn = cm[0];
+#pragma unroll
+    for (int j = 1; j < CH; j++) mn = fminf(mn, cm[j]);
     mn = wave_allreduce_min(mn);
     if (lean_norm_ok(mn)) {
         const LeanNorm nrm(mn);
@@ -337,40 +366,37 @@ __device__ __forceinline__ void lean_scan_item(const T (&c)[2 * N], const T (&zr
             if constexpr (PEAKS) peak_pick<CH>(qf, lane, P, M, xs, pk_val_item, pk_loc_item);
         } else {
             int pos = INT_MAX;
-            if constexpr (!STORE) {
-                // angles only: the tie compare and the scalar position search, nothing else
-#pragma unroll
-                for (int j = 0; j < CH; j++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const unsigned long long at_max = __builtin_amdgcn_ballot_w64(qf[j][e] <= nrm.q_hi);
-                        const int cand = at_max ? (4 * (int)__builtin_ctzll(at_max) + 256 * j + e) : INT_MAX;
-                        pos = min(pos, cand);
-                    }
-            } else
+            float keep = 0.f;
 #pragma unroll
             for (int j = 0; j < CH; j++) {
                 typedef float v2f __attribute__((ext_vector_type(2)));
-                float t[4], db[4];
-                {
+                float db[4];
+                if constexpr (STORE) {
                     v2f a = {qf[j][0], qf[j][1]}, b = {qf[j][2], qf[j][3]};
                     a *= nrm.inv_up; b *= nrm.inv_up;                            // v_pk_mul_f32
                     a = v2f{__log2f(a.x), __log2f(a.y)}; b = v2f{__log2f(b.x), __log2f(b.y)};
                     a *= -kDbPerLog2; b *= -kDbPerLog2;                          // v_pk_mul_f32
-                    t[0] = a.x; t[1] = a.y; t[2] = b.x; t[3] = b.y;
+                    db[0] = a.x; db[1] = a.y; db[2] = b.x; db[3] = b.y;
                 }
+                // lanes that hold a tied angle in this chunk (wave-uniform mask, zero for most chunks)
+                const unsigned long long tied_lanes = __builtin_amdgcn_ballot_w64(cm[j] <= nrm.q_hi);
+                if (tied_lanes != 0ull) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    // the tie compare lands in an SGPR pair: the position search is scalar work beside the vector pipe, and
-                    // the same mask drives the select that puts exactly 0 dB on the tied angles (written as
-                    // `tie ? 0.0f : d` the compiler issues a second, inverted compare per angle)
-                    const unsigned long long at_max = __builtin_amdgcn_ballot_w64(qf[j][e] <= nrm.q_hi);
-                    const int cand = at_max ? (4 * (int)__builtin_ctzll(at_max) + 256 * j + e) : INT_MAX;
-                    pos = min(pos, cand);
-                    asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(db[e]) : "v"(t[e]), "s"(at_max));
+                    for (int e = 0; e < 4; e++) {
+                        // the tie compare lands in an SGPR pair: the position search is scalar work, and the same mask drives
+                        // the select that puts exactly 0 dB on the tied angles (written as `tie ? 0.0f : d` the compiler issues
+                        // a second, inverted compare per angle)
+                        const unsigned long long at_max = __builtin_amdgcn_ballot_w64(qf[j][e] <= nrm.q_hi);
+                        const int cand = at_max ? (4 * (int)__builtin_ctzll(at_max) + 256 * j + e) : INT_MAX;
+                        pos = min(pos, cand);
+                        if constexpr (STORE) asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(db[e]) : "v"(db[e]), "s"(at_max));
+                    }
                 }
-                store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(db[0], db[1], db[2], db[3]));
+                if constexpr (STORE && ABL == 1) keep += (db[0] + db[1]) + (db[2] + db[3]);
+                else if constexpr (STORE)
+                    store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(db[0], db[1], db[2], db[3]));
             }
+            if constexpr (ABL == 1) { if (keep == 12345.678f) row[lane] = keep; }      // keeps the arithmetic alive; never true
             // (the minimum itself always ties, so pos is a valid angle; the clamp only keeps a broken invariant from
             // turning into a wild address)
             if constexpr (PEAKS) {
@@ -378,7 +404,7 @@ __device__ __forceinline__ void lean_scan_item(const T (&c)[2 * N], const T (&zr
             }
         }
     } else {
-        lean_scan_item_irregular<N, CH, T, MULTI, PEAKS>(c, qf, ztab, row, xs, pk_val_item, pk_loc_item, M, lane);
+        lean_scan_item_irregular<N, CH, T, MULTI, PEAKS>(Q, ztab, row, xs, pk_val_item, pk_loc_item, M, lane);
     }
 }
 
@@ -388,14 +414,13 @@ __device__ __forceinline__ void lean_scan_item(const T (&c)[2 * N], const T (&zr
 // to 152 VGPRs, i.e. from four to three waves per SIMD next to the covariance kernel's 120-VGPR waves: 2.5 us per
 // pipeline step)
 template <int N, int CH, typename T, bool MULTI, bool PEAKS>
-__device__ __forceinline__ void lean_scan_item_irregular(const T (&c)[2 * N], float (&qf)[CH][4], const T *__restrict__ ztab,
+__device__ __forceinline__ void lean_scan_item_irregular(const LeanQ<N, T> &Q, const T *__restrict__ ztab,
                                                          float *__restrict__ row, const float *__restrict__ xs,
                                                          float *__restrict__ pk_val_item, float *__restrict__ pk_loc_item,
                                                          int M, int lane)
 {
     constexpr int P = 256 * CH;
-    (void)qf;
-    auto q_at = [&](int i) { return (float)null_spectrum<N, T>(c, (T)ztab[2 * i], (T)ztab[2 * i + 1]); };
+    auto q_at = [&](int i) { return (float)Q((T)ztab[2 * i], (T)ztab[2 * i + 1]); };
     float mx = -INFINITY;
 #pragma unroll 1
     for (int k = 0; k < 4 * CH; k++) mx = fmaxf(mx, 1.0f / q_at(4 * lane + 256 * (k >> 2) + (k & 3)));
@@ -438,15 +463,27 @@ __device__ __forceinline__ void lean_load_table(const T *__restrict__ ztab, int 
             const int i = 4 * lane + 256 * j + e;
             zr[j][e] = ztab[2 * i]; zi[j][e] = ztab[2 * i + 1];
         }
+    // the table must have ARRIVED before the item loop: otherwise the compiler's wait for it sits inside the loop, where
+    // (gfx9 has one counter for loads and stores) it also waits for the previous item's four row stores, i.e. every wave
+    // would drain its stores before the second half of every pass 1
+#pragma unroll
+    for (int j = 0; j < CH; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) asm volatile("" :: "v"(zr[j][e]), "v"(zi[j][e]));
 }
 
-template <int N, int CH, typename T, bool MULTI = false, bool PEAKS = true, bool STORE = true>
+// item_shift: 0 = wave w takes items w, w + n_waves, ... (every wave the same count at the benchmark batch); 4 = a wave
+// takes SIXTEEN consecutive items per turn of the grid (item = (k >> 4) 16 n_waves + 16 w + (k & 15)): at large batches the
+// rows a wave writes are then one 64 KiB run instead of 4 KiB every n_waves rows (measured, stores alone: 188-196 us
+// against 213-219 us per 262144 rows of 4 KiB).
+template <int N, int CH, typename T, bool MULTI = false, bool PEAKS = true, bool STORE = true, int ABL = 0>
 __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                                float *__restrict__ spec, int n_items,
                                                                const float *__restrict__ xaxis, float *__restrict__ pk_val,
-                                                               float *__restrict__ pk_loc, int M)
+                                                               float *__restrict__ pk_loc, int M, int item_shift, int prefetch2)
 {
     constexpr int P = 256 * CH;
+    constexpr int RL = LeanRecord<N, T>::kLen;
     __shared__ float xs[P];
     if constexpr (PEAKS) {
         for (int i = threadIdx.x; i < P; i += blockDim.x) xs[i] = xaxis[i];
@@ -457,33 +494,38 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
     const int n_waves = gridDim.x * (blockDim.x / kWave);
     T zr[CH][4], zi[CH][4];
     lean_load_table<CH, T>(ztab, lane, zr, zi);
-    // coefficient records arrive through scalar loads; the next item's record is requested before this item's
-    // arithmetic so that its latency hides behind it
-    T c[2 * N], c_next[2 * N];
-    if (wave < n_items) {
+    const int sub_mask = (1 << item_shift) - 1;
+    auto item_of = [&](int k) { return (k >> item_shift) * (n_waves << item_shift) + (wave << item_shift) + (k & sub_mask); };
+    const int per_turn = n_waves << item_shift;
+    const int turns = ((n_items + per_turn - 1) / per_turn) << item_shift;
+    // coefficient records arrive through scalar loads, requested TWO items ahead: under a write-saturated memory system a
+    // read takes longer than one item's arithmetic (DOA_SCAN_PREFETCH=1 in lab builds: one item ahead, the round-2 form)
+    T c[RL], c_n1[RL], c_n2[RL];
+    auto fetch = [&](int k, T (&dst)[RL]) {
+        const int it = item_of(k);
+        if (k < turns && it < n_items) {
 #pragma unroll
-        for (int k = 0; k < 2 * N; k++) c_next[k] = coef[(size_t)wave * (2 * N) + k];
-    }
-    for (int item = wave; item < n_items; item += n_waves) {
-#pragma unroll
-        for (int k = 0; k < 2 * N; k++) c[k] = c_next[k];
-        const int nxt = item + n_waves;
-        if (nxt < n_items) {
-#pragma unroll
-            for (int k = 0; k < 2 * N; k++) c_next[k] = coef[(size_t)nxt * (2 * N) + k];
+            for (int i = 0; i < RL; i++) dst[i] = coef[(size_t)it * RL + i];
         }
-        lean_scan_item<N, CH, T, MULTI, PEAKS, STORE>(c, zr, zi, ztab, spec + (size_t)item * P, xs, pk_val + (size_t)item * M,
-                                                      pk_loc + (size_t)item * M, M, lane);
+    };
+    fetch(0, c_n1);
+    if (prefetch2) fetch(1, c_n2);
+    for (int k = 0; k < turns; k++) {
+        const int item = item_of(k);
+#pragma unroll
+        for (int i = 0; i < RL; i++) c[i] = c_n1[i];
+        if (prefetch2) {
+#pragma unroll
+            for (int i = 0; i < RL; i++) c_n1[i] = c_n2[i];
+            fetch(k + 2, c_n2);
+        } else {
+            fetch(k + 1, c_n1);
+        }
+        if (item < n_items)
+            lean_scan_item<N, CH, T, MULTI, PEAKS, STORE, ABL>(c, zr, zi, ztab, spec + (size_t)item * P, xs, pk_val + (size_t)item * M,
+                                                          pk_loc + (size_t)item * M, M, lane);
     }
 }
-
-}  // namespace doa
-#ifdef DOA_LAB
-#include "music_scan_lab.hpp"
-#include <algorithm>
-#include <vector>
-#endif
-namespace doa {
 
 // Long spectra (P % 4 == 0, any length): one wave per item, 4 consecutive angles per lane per 256-angle
 // chunk, chunks in a ROLLED loop, Q parked as float in the output row between the two passes (minimum first,
@@ -716,21 +758,24 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
     // two items per wave at the benchmark batch: the z table is loaded once per wave and the next
     // item's coefficient record is prefetched behind the current item's arithmetic
     int blocks = (n_items + waves_per_block - 1) / waves_per_block;
-    static const int wpc = [] { const char *e = getenv("DOA_SCAN_WAVES_PER_CU"); return e ? atoi(e) : 8; }();
+    const int wpc = DOA_LAB_ENV_INT("DOA_SCAN_WAVES_PER_CU", 8);
     const int max_blocks = cu_count() * wpc / waves_per_block;
     if (blocks > max_blocks) blocks = max_blocks;
     dim3 grid(blocks), block(waves_per_block * kWave);
-    // the lean benchmark-shape kernel (see music_scan_peak1_kernel)
-    static const int lean = [] { const char *e = getenv("DOA_SCAN_LEAN"); return e ? atoi(e) : 1; }();
-    // (also without a peak pick -- the stand-alone MUSIC_lin_array block -- so that block and pipeline produce the
-    // same spectrum bit for bit: same kernel, same arithmetic)
-    if (lean && aligned && !q && n_ant == N && (P == 256 || P == 512 || P == 1024)) {
+    // the lean benchmark-shape kernel (see music_scan_peak1_kernel); also without a peak pick -- the stand-alone
+    // MUSIC_lin_array block -- so that block and pipeline produce the same spectrum bit for bit: same kernel, same
+    // arithmetic.  For N <= 4 in double it reads the pre-transformed records (pk.cheb), which the caller must supply.
+    constexpr bool kPre = LeanRecord<N, T>::kPre;
+    if (aligned && !q && n_ant == N && (P == 256 || P == 512 || P == 1024) && (!kPre || pk.cheb)) {
+        const T *rec = kPre ? static_cast<const T *>(pk.cheb) : co;
         int lb = (n_items + waves_per_block - 1) / waves_per_block;
-        // 12 waves per CU: the kernel is vector-pipe bound at large batches (compute without stores 219 us, stores
-        // without compute 193 us, both 268 us per 262144 items on one box; 8 waves: 247 / 210 / 282), so a third wave
-        // per SIMD to fill the DPP-reduction and v_log latencies pays; 16 measured no better
-        static const int lwpc = [] { const char *e = getenv("DOA_SCAN_LEAN_WAVES_PER_CU"); return e ? atoi(e) : 12; }();
+        // Waves per CU.  Alone at large batches the kernel runs within a few per cent of the rate its row stores reach on
+        // their own, and what that rate is depends on how many waves store at once (tools/lab/store_rates.hip: 4 KiB rows
+        // from 8 / 12 / 16 waves per CU: 203 / 180 / 214 us per GiB).
+        const int lwpc = DOA_LAB_ENV_INT("DOA_SCAN_LEAN_WAVES_PER_CU", 12);
         const int cap = cu_count() * lwpc / waves_per_block;
+        int item_shift = 0;
+        const int prefetch2 = DOA_LAB_ENV_INT("DOA_SCAN_PREFETCH", 2) >= 2;
         if (lb > cap) {
             // every wave takes the same number of items (4096 items on a cap of 3072 waves would be one round of 3072 and a
             // second of 1024 with two thirds of the chip idle: 2048 waves with two items each instead)
@@ -738,86 +783,61 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
             const int per_wave = (n_items + cap_waves - 1) / cap_waves;
             const int waves = (n_items + per_wave - 1) / per_wave;
             lb = (waves + waves_per_block - 1) / waves_per_block;
+            // sixteen consecutive items per wave and turn once every wave has at least two such runs to do
+            const int shift_env = DOA_LAB_ENV_INT("DOA_SCAN_ITEM_SHIFT", -1);
+            if (per_wave >= 32) { lb = cap; item_shift = 4; }
+            if (shift_env >= 0) { item_shift = shift_env; if (shift_env == 0) lb = (waves + waves_per_block - 1) / waves_per_block; else lb = cap; }
         }
         dim3 lgrid(lb);
-#define DOA_LEAN_LAUNCH(CH_, MULTI_, PEAKS_)                                                                       \
-    hipLaunchKernelGGL((music_scan_peak1_kernel<N, CH_, T, MULTI_, PEAKS_>), lgrid, block, 0, st, co, z, sp, n_items,  \
-                       pk.xaxis, pk.val, pk.loc, pk.M)
-#define DOA_LEAN_CH(MULTI_, PEAKS_)                                                                                \
+#define DOA_LEAN_LAUNCH(CH_, MULTI_, PEAKS_, STORE_)                                                               \
+    hipLaunchKernelGGL((music_scan_peak1_kernel<N, CH_, T, MULTI_, PEAKS_, STORE_>), lgrid, block, 0, st, rec, z, sp,   \
+                       n_items, pk.xaxis, pk.val, pk.loc, pk.M, item_shift, prefetch2)
+#define DOA_LEAN_CH(MULTI_, PEAKS_, STORE_)                                                                        \
     do {                                                                                                           \
-        if (P == 256) DOA_LEAN_LAUNCH(1, MULTI_, PEAKS_);                                                          \
-        else if (P == 512) DOA_LEAN_LAUNCH(2, MULTI_, PEAKS_);                                                     \
-        else DOA_LEAN_LAUNCH(4, MULTI_, PEAKS_);                                                                   \
+        if (P == 256) DOA_LEAN_LAUNCH(1, MULTI_, PEAKS_, STORE_);                                                  \
+        else if (P == 512) DOA_LEAN_LAUNCH(2, MULTI_, PEAKS_, STORE_);                                             \
+        else DOA_LEAN_LAUNCH(4, MULTI_, PEAKS_, STORE_);                                                           \
     } while (0)
 #ifdef DOA_LAB
         if constexpr (N == 4 && sizeof(T) == 8) {
-            static const int variant = [] { const char *e = getenv("DOA_SCAN_VARIANT"); return e ? atoi(e) : -1; }();
-            if (variant >= 0 && P == 1024 && pk.val && pk.store && pk.M == 1) {
-                static unsigned long long *d_stamps = nullptr;
-                if ((variant & 64) && !d_stamps) (void)hipMalloc(&d_stamps, sizeof(unsigned long long) * 2 * 65536);
-                bool ok = false;
-#define DOA_LAB_VAR(V_)                                                                                               \
-    if (variant == (V_)) {                                                                                            \
-        hipLaunchKernelGGL((music_scan_peak1_lab_kernel<4, 4, T, (V_)>), lgrid, block, 0, st, co, z, sp, n_items, pk.xaxis, \
-                           pk.val, pk.loc, d_stamps);                                                                 \
-        ok = true;                                                                                                    \
-    }
-                DOA_LAB_VAR(0) DOA_LAB_VAR(1) DOA_LAB_VAR(2) DOA_LAB_VAR(3) DOA_LAB_VAR(4) DOA_LAB_VAR(6) DOA_LAB_VAR(7)
-                DOA_LAB_VAR(8) DOA_LAB_VAR(9) DOA_LAB_VAR(11) DOA_LAB_VAR(15) DOA_LAB_VAR(16) DOA_LAB_VAR(23) DOA_LAB_VAR(32)
-                DOA_LAB_VAR(33) DOA_LAB_VAR(41) DOA_LAB_VAR(71) DOA_LAB_VAR(79)
-#undef DOA_LAB_VAR
-                if (ok) {
-                    if (variant & 64) {
-                        static int printed = 0;
-                        if (printed < 3 && hipStreamSynchronize(st) == hipSuccess) {
-                            const int nw = lb * waves_per_block;
-                            std::vector<unsigned long long> h(2 * (size_t)nw);
-                            (void)hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
-                            std::vector<double> ghz;
-                            for (int w = 0; w < nw; w++) if (h[2 * w + 1]) ghz.push_back((double)h[2 * w] / ((double)h[2 * w + 1] * 10.0));
-                            std::sort(ghz.begin(), ghz.end());
-                            if (!ghz.empty()) fprintf(stderr, "[lab] scan kernel in-kernel clock: median %.3f GHz (min %.3f max %.3f) over %zu waves, n_items %d\n",
-                                                      ghz[ghz.size() / 2], ghz.front(), ghz.back(), ghz.size(), n_items);
-                            printed++;
-                        }
-                    }
-                    return true;
-                }
+            // ablations of the graded kernel (results invalid): DOA_SCAN_ABLATE=1 no row stores, =2 row stores only
+            const int ablate = DOA_LAB_ENV_INT("DOA_SCAN_ABLATE", 0);
+            if (ablate && P == 1024 && pk.val && pk.store && pk.M == 1) {
+                if (ablate == 1)
+                    hipLaunchKernelGGL((music_scan_peak1_kernel<4, 4, T, false, true, true, 1>), lgrid, block, 0, st, rec, z, sp, n_items,
+                                       pk.xaxis, pk.val, pk.loc, pk.M, item_shift, prefetch2);
+                else
+                    hipLaunchKernelGGL((music_scan_peak1_kernel<4, 4, T, false, true, true, 2>), lgrid, block, 0, st, rec, z, sp, n_items,
+                                       pk.xaxis, pk.val, pk.loc, pk.M, item_shift, prefetch2);
+                return true;
             }
         }
 #endif
-        if (!pk.val) DOA_LEAN_CH(false, false);
-        else if (!pk.store) {
-            // angles only (sp is scratch for irregular rows)
-#define DOA_LEAN_NOSTORE(CH_, MULTI_)                                                                              \
-    hipLaunchKernelGGL((music_scan_peak1_kernel<N, CH_, T, MULTI_, true, false>), lgrid, block, 0, st, co, z, sp, n_items, \
-                       pk.xaxis, pk.val, pk.loc, pk.M)
-            if (pk.M == 1) { if (P == 256) DOA_LEAN_NOSTORE(1, false); else if (P == 512) DOA_LEAN_NOSTORE(2, false); else DOA_LEAN_NOSTORE(4, false); }
-            else { if (P == 256) DOA_LEAN_NOSTORE(1, true); else if (P == 512) DOA_LEAN_NOSTORE(2, true); else DOA_LEAN_NOSTORE(4, true); }
-#undef DOA_LEAN_NOSTORE
+        if (!pk.val) DOA_LEAN_CH(false, false, true);
+        else if (!pk.store) {                                   // angles only (sp is scratch for irregular rows)
+            if (pk.M == 1) DOA_LEAN_CH(false, true, false);
+            else DOA_LEAN_CH(true, true, false);
         }
-        else if (pk.M == 1) DOA_LEAN_CH(false, true);
-        else DOA_LEAN_CH(true, true);
+        else if (pk.M == 1) DOA_LEAN_CH(false, true, true);
+        else DOA_LEAN_CH(true, true, true);
 #undef DOA_LEAN_CH
 #undef DOA_LEAN_LAUNCH
         return pk.val != nullptr;
     }
-    // long spectra without diagnostics and without a fused peak pick: the streaming two-pass kernel
-    static const int stream_on = [] { const char *e = getenv("DOA_SCAN_STREAM"); return e ? atoi(e) : 1; }();
-    // P > 2048 in double: peak_pick<16> on a register-resident row makes the fused kernel a 511-VGPR, one-wave-
-    // per-SIMD kernel (135 us per 4096 items at N = 16); the streaming scan (~30 us) followed by the stand-alone
-    // find_local_max kernel (~47 us) is faster, so the peak pick is left to the caller there (returns false).
-    if (stream_on && aligned && P > 2048 && sizeof(T) == 8 && !q) {
-        // with the peak pick wanted (the pipeline) and P a multiple of 64 up to 4096: scan + K5 in one launch, the row
-        // written once (DOA_SCAN_LONG_FUSED=0: the two-launch form)
-        static const int long_fused = [] { const char *e = getenv("DOA_SCAN_LONG_FUSED"); return e ? atoi(e) : 1; }();
-        if (long_fused && pk.val && pk.M >= 1 && P % 64 == 0 && P <= 4096) {
+    // long spectra without diagnostics: P > 2048 in double.  peak_pick<16> on a register-resident row makes the fused fast
+    // kernel a 511-VGPR, one-wave-per-SIMD kernel (135 us per 4096 items at N = 16); instead:
+    if (aligned && P > 2048 && sizeof(T) == 8 && !q) {
+        // with the peak pick wanted (the pipeline) and P a multiple of 64 up to 4096: scan + K5 in one launch, the row staged in
+        // LDS and written once (the two-launch form it replaced moved the row through HBM four times)
+        if (pk.val && pk.M >= 1 && P % 64 == 0 && P <= 4096) {
             int fb = (n_items + waves_per_block - 1) / waves_per_block;
             if (fb > cu_count() * 2) fb = cu_count() * 2;                 // 64 KiB of LDS per workgroup: two per CU
             hipLaunchKernelGGL((music_scan_peak_long_kernel<N, T>), dim3(fb), block, 0, st, co, z, sp, P, n_items, n_ant,
                                pk.xaxis, pk.val, pk.loc, pk.M);
             return true;
         }
+        // spectrum only (the stand-alone block), or lengths the fused kernel does not take: the rolled two-pass kernel; the
+        // peak pick, if any, is left to the caller (returns false)
         int sb = (n_items + waves_per_block - 1) / waves_per_block;
         if (sb > cu_count() * 16 / waves_per_block) sb = cu_count() * 16 / waves_per_block;
         hipLaunchKernelGGL((music_scan_stream_kernel<N, T>), dim3(sb), block, 0, st, co, z, sp, P, n_items, n_ant);

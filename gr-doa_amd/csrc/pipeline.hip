@@ -25,7 +25,7 @@ struct doa_music_pipeline {
     unsigned stages = 7;           // bit 0 K1, bit 1 K2+K3, bit 2 K4+K5 (doa_music_pipeline_set_stages)
     doa::MusicTables music;
     doa::PeakTables peaks;
-    doa::DevBuf d_cov, d_coef, d_spec, d_scratch, d_gain;
+    doa::DevBuf d_cov, d_coef, d_cheb, d_spec, d_scratch, d_gain;
     bool has_gain = false;
     // host-pointer entry point only: two copy/compute lanes
     hipStream_t hst[2] = {nullptr, nullptr};
@@ -33,41 +33,85 @@ struct doa_music_pipeline {
     doa::DevBuf d_work[2];          // K1's piece sums (overlapping windows), one per copy/compute lane
     doa::PinnedBuf h_stage;         // scheduler-sized calls: one page-locked staging buffer, one copy each way
     int fail_chunk = -1;            // doa_music_pipeline_inject_failure: one-shot, host-pointer entry only (tests)
+    // doa_music_pipeline_work_dev_batches: the library's own overlap lanes (streams + one workspace each)
+    struct Lane {
+        hipStream_t st = nullptr;
+        bool own_stream = true;         // false: adopted from the caller (doa_music_pipeline_set_lane_streams)
+        hipEvent_t done = nullptr;
+        doa::DevBuf coef, cheb, cov, spec, work, scratch;
+    };
+    static constexpr int kMaxLanes = 8;
+    Lane lanes[kMaxLanes];
+    int n_lanes = 4;
+    int next_lane = 0;              // lanes keep rotating across calls
+    hipEvent_t fork_ev = nullptr;
 };
 
-// K1 -> EVD -> scan (+ peak) for n items on `st`; coefficient records at item offset `coef_off` of the
-// handle's workspace (chunks in flight on different streams must not share records).
-// `spec` == nullptr: nobody wants the spectrum (angles-only call): the handle's own buffer serves as scratch and the lean
+// what one K1 -> EVD -> scan chain needs besides its inputs and outputs
+struct PipeWs {
+    void *coef;             // coefficient records of the chain's items
+    void *cheb;             // N <= 4, double: their pre-transformed twins for the lean scan kernel (else NULL)
+    void *spec_scratch;     // P floats per item, used when the caller does not want the spectrum
+    void *work;             // K1's piece sums (overlapping windows), or NULL
+    doa::DevBuf *scratch;   // grown on demand: the serial peak pick of unusual vector lengths
+    size_t scratch_item_off;
+};
+
+// K1 -> EVD -> scan (+ peak) for n items on `st` with the workspace `ws`.
+// `spec` == nullptr: nobody wants the spectrum (angles-only call): ws.spec_scratch serves as scratch and the lean
 // scan kernel neither converts the row to dB nor writes it.
-static int run_dev(doa_music_pipeline *h, int n, const void *const *d_in, void *cov, void *spec, void *mx, void *am,
-                   size_t item_off, hipStream_t st, int lane = 0)
+static int run_k1(doa_music_pipeline *h, int n, const void *const *d_in, void *cov, const PipeWs &ws, hipStream_t st)
+{
+    if (~h->stages & 1u) return DOA_OK;         // doa_music_pipeline_set_stages (profiling aid; all stages in production)
+    return doa::launch_autocorrelate(h->N, h->K, h->ovl, h->avg, n, d_in, cov, st, h->has_gain ? h->d_gain.p : nullptr, ws.work);
+}
+static int run_evd_scan(doa_music_pipeline *h, int n, void *cov, void *spec, void *mx, void *am, const PipeWs &ws, hipStream_t st)
 {
     const bool store_spec = (spec != nullptr);
-    if (!spec) spec = static_cast<char *>(h->d_spec.p) + item_off * h->peaks.L * sizeof(float);
-    const unsigned skip = ~h->stages & 7u;      // doa_music_pipeline_set_stages (profiling aid; 0 in production)
+    if (!spec) spec = ws.spec_scratch;
+    const unsigned skip = ~h->stages & 7u;
     int rc = DOA_OK;
-    if (!(skip & 1)) rc = doa::launch_autocorrelate(h->N, h->K, h->ovl, h->avg, n, d_in, cov, st,
-                                                     h->has_gain ? h->d_gain.p : nullptr, h->d_work[lane].p);
-    if (rc != DOA_OK) return rc;
     const bool dbl = (h->bits == 64);
-    void *coef = static_cast<char *>(h->d_coef.p) + item_off * doa::coef_stride(h->N) * (dbl ? sizeof(double) : sizeof(float));
+    void *coef = ws.coef;
     if (!(skip & 2))
-        rc = doa::launch_music_evd(h->N, h->music.M, n, cov, dbl ? nullptr : coef, dbl ? coef : nullptr, nullptr, h->bits, st);
+        rc = doa::launch_music_evd(h->N, h->music.M, n, cov, dbl ? nullptr : coef, dbl ? coef : nullptr, nullptr, h->bits, st, ws.cheb);
     if (rc != DOA_OK) return rc;
     bool peaks_done = false;
     if (skip & 4) return n;
-    rc = doa::launch_music_scan(h->music, h->bits, n, coef, spec, nullptr, st, &h->peaks, mx, am, &peaks_done, store_spec);
+    rc = doa::launch_music_scan(h->music, h->bits, n, coef, spec, nullptr, st, &h->peaks, mx, am, &peaks_done, store_spec, ws.cheb);
     if (rc != DOA_OK) return rc;
     if (peaks_done) return n;
     if (doa::find_local_max_fast_ok(h->peaks.L, spec)) {
         rc = doa::launch_find_local_max(h->peaks, n, spec, mx, am, st);
     } else {
-        rc = h->d_scratch.reserve((size_t)h->max_batch * h->peaks.L);
+        rc = ws.scratch->reserve((size_t)h->max_batch * h->peaks.L);
         if (rc == DOA_OK)
             rc = doa::launch_find_local_max_serial(h->peaks, n, spec, mx, am,
-                                                   static_cast<char *>(h->d_scratch.p) + item_off * h->peaks.L, st);
+                                                   static_cast<char *>(ws.scratch->p) + ws.scratch_item_off * h->peaks.L, st);
     }
     return rc == DOA_OK ? n : rc;
+}
+static int run_ws(doa_music_pipeline *h, int n, const void *const *d_in, void *cov, void *spec, void *mx, void *am,
+                  const PipeWs &ws, hipStream_t st)
+{
+    const int rc = run_k1(h, n, d_in, cov, ws, st);
+    return rc != DOA_OK ? rc : run_evd_scan(h, n, cov, spec, mx, am, ws, st);
+}
+
+// the handle's own single workspace (work_dev and the host-pointer entry): records / scratch rows at item offset
+// `item_off` (chunks in flight on different streams must not share them)
+static int run_dev(doa_music_pipeline *h, int n, const void *const *d_in, void *cov, void *spec, void *mx, void *am,
+                   size_t item_off, hipStream_t st, int lane = 0)
+{
+    const bool dbl = (h->bits == 64);
+    PipeWs ws;
+    ws.coef = static_cast<char *>(h->d_coef.p) + item_off * doa::coef_stride(h->N) * (dbl ? sizeof(double) : sizeof(float));
+    ws.cheb = h->d_cheb.p ? static_cast<char *>(h->d_cheb.p) + item_off * doa::kChebRecord * sizeof(double) : nullptr;
+    ws.spec_scratch = static_cast<char *>(h->d_spec.p) + item_off * h->peaks.L * sizeof(float);
+    ws.work = h->d_work[lane].p;
+    ws.scratch = &h->d_scratch;
+    ws.scratch_item_off = item_off;
+    return run_ws(h, n, d_in, cov, spec, mx, am, ws, st);
 }
 
 extern "C" {
@@ -100,6 +144,7 @@ doa_music_pipeline_t *doa_music_pipeline_create(int inputs, int snapshot_size, i
     if (rc == DOA_OK) rc = h->peaks.build(num_targets, pspectrum_len, 0.0f, 180.0f);
     if (rc == DOA_OK) rc = h->d_cov.reserve((size_t)max_batch * inputs * inputs * sizeof(float2));
     if (rc == DOA_OK) rc = h->d_coef.reserve((size_t)max_batch * doa::coef_stride(inputs) * sizeof(double));
+    if (rc == DOA_OK && doa::music_uses_cheb(inputs, h->bits)) rc = h->d_cheb.reserve((size_t)max_batch * doa::kChebRecord * sizeof(double));
     if (rc == DOA_OK) rc = h->d_spec.reserve((size_t)max_batch * pspectrum_len * sizeof(float));
     if (const size_t ws = doa::autocorrelate_workspace_bytes(inputs, snapshot_size, overlap_size, max_batch); ws && rc == DOA_OK)
         rc = h->d_work[0].reserve(ws);
@@ -115,12 +160,18 @@ void doa_music_pipeline_destroy(doa_music_pipeline_t *h)
     if (!h) return;
     h->music.release();
     h->peaks.release();
-    h->d_cov.release(); h->d_coef.release(); h->d_spec.release(); h->d_scratch.release(); h->d_gain.release();
+    h->d_cov.release(); h->d_coef.release(); h->d_cheb.release(); h->d_spec.release(); h->d_scratch.release(); h->d_gain.release();
     h->d_res.release(); h->h_stage.release();
     for (auto &b : h->d_work) b.release();
     for (auto &b : h->d_in) b.release();
     for (auto st : h->hst)
         if (st) (void)hipStreamDestroy(st);
+    for (auto &l : h->lanes) {
+        l.coef.release(); l.cheb.release(); l.cov.release(); l.spec.release(); l.work.release(); l.scratch.release();
+        if (l.done) (void)hipEventDestroy(l.done);
+        if (l.st && l.own_stream) (void)hipStreamDestroy(l.st);
+    }
+    if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     delete h;
 }
 
@@ -170,6 +221,133 @@ int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput_items, cons
     void *spec = d_spectrum_out;                       // NULL = angles only (run_dev)
     return run_dev(h, noutput_items, d_input_items, cov, spec, d_max_out, d_argmax_out, 0,
                    static_cast<hipStream_t>(hip_stream));
+}
+
+int doa_music_pipeline_set_lanes(doa_music_pipeline_t *h, int n_lanes)
+{
+    doa::clear_error();
+    if (!h || n_lanes < 1 || n_lanes > doa_music_pipeline::kMaxLanes) {
+        doa::set_error("music_pipeline_set_lanes: need 1 <= n_lanes <= %d", doa_music_pipeline::kMaxLanes);
+        return DOA_ERR_INVALID_ARG;
+    }
+    h->n_lanes = n_lanes;
+    h->next_lane = 0;
+    return DOA_OK;
+}
+
+int doa_music_pipeline_work_dev_batches(doa_music_pipeline_t *h, int n_batches, int noutput_items,
+                                        const void *const *d_input_items, void *const *d_cov_out,
+                                        void *const *d_spectrum_out, void *const *d_max_out, void *const *d_argmax_out,
+                                        void *hip_stream)
+{
+    doa::clear_error();
+    if (!h || n_batches < 0 || noutput_items < 0 || !d_input_items || !d_max_out || !d_argmax_out) {
+        doa::set_error("music_pipeline_work_dev_batches: bad arguments");
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (noutput_items > h->max_batch) {
+        doa::set_error("music_pipeline_work_dev_batches: noutput_items=%d exceeds max_batch=%d", noutput_items, h->max_batch);
+        return DOA_ERR_INVALID_ARG;
+    }
+    for (int b = 0; b < n_batches; b++)
+        if (noutput_items > 0 && (!d_max_out[b] || !d_argmax_out[b])) {
+            doa::set_error("music_pipeline_work_dev_batches: batch %d has no peak output pointers", b);
+            return DOA_ERR_INVALID_ARG;
+        }
+    if (n_batches == 0 || noutput_items == 0) return 0;
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
+    hipStream_t caller = static_cast<hipStream_t>(hip_stream);
+    const int N = h->N;
+    if (h->n_lanes == 1 && hip_stream != DOA_STREAM_DETACHED) {     // nothing to overlap: the caller's stream itself, no events
+        for (int b = 0; b < n_batches; b++) {
+            void *cov = (d_cov_out && d_cov_out[b]) ? d_cov_out[b] : h->d_cov.p;
+            const int rc = run_dev(h, noutput_items, d_input_items + (size_t)b * N, cov, d_spectrum_out ? d_spectrum_out[b] : nullptr,
+                                   d_max_out[b], d_argmax_out[b], 0, caller);
+            if (rc < 0) return rc;
+        }
+        return n_batches * noutput_items;
+    }
+    // lanes: streams, events and workspaces, created on first use
+    const bool dbl = (h->bits == 64);
+    const bool detached = (hip_stream == DOA_STREAM_DETACHED);
+    bool need_cov = !d_cov_out, need_spec = !d_spectrum_out;
+    for (int b = 0; b < n_batches && !(need_cov && need_spec); b++) {
+        if (d_cov_out && !d_cov_out[b]) need_cov = true;
+        if (d_spectrum_out && !d_spectrum_out[b]) need_spec = true;
+    }
+    if (!detached && !h->fork_ev) DOA_HIP_TRY(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+    const size_t work_bytes = doa::autocorrelate_workspace_bytes(N, h->K, h->ovl, h->max_batch);
+    const int L = h->n_lanes;
+    for (int l = 0; l < L; l++) {
+        auto &ln = h->lanes[l];
+        if (!ln.st) { DOA_HIP_TRY(hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking)); ln.own_stream = true; }
+        if (!detached && !ln.done) DOA_HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+        int rc = ln.coef.reserve((size_t)h->max_batch * doa::coef_stride(N) * (dbl ? sizeof(double) : sizeof(float)));
+        if (rc == DOA_OK && doa::music_uses_cheb(N, h->bits)) rc = ln.cheb.reserve((size_t)h->max_batch * doa::kChebRecord * sizeof(double));
+        if (rc == DOA_OK && need_cov) rc = ln.cov.reserve((size_t)h->max_batch * N * N * sizeof(float2));
+        if (rc == DOA_OK && need_spec) rc = ln.spec.reserve((size_t)h->max_batch * h->peaks.L * sizeof(float));
+        if (rc == DOA_OK && work_bytes) rc = ln.work.reserve(work_bytes);
+        if (rc != DOA_OK) return rc;
+    }
+    // Batch b of this call runs its K1 -> EVD -> scan chain on lane (next_lane + b) % L, in order on that lane; the
+    // rotation carries over from call to call.  Attached to a stream, the call forks (every lane waits for what the caller's
+    // stream holds now: one event) and joins (the caller's stream waits for every lane: one event per lane) ONCE, whatever
+    // n_batches is.  Cross-stream events are expensive on this runtime (~80 us per fork + join, and an event per batch
+    // degrades the lanes to the serial rate -- measured), which is why there is no finer-grained schedule
+    // here and why the detached form exists.
+    const int lane0 = h->next_lane % L;
+    h->next_lane = (lane0 + n_batches) % L;
+    const int used = n_batches < L ? n_batches : L;
+    if (!detached) {
+        DOA_HIP_TRY(hipEventRecord(h->fork_ev, caller));
+        for (int u = 0; u < used; u++) DOA_HIP_TRY(hipStreamWaitEvent(h->lanes[(lane0 + u) % L].st, h->fork_ev, 0));
+    }
+    int rc = DOA_OK;
+    for (int b = 0; b < n_batches && rc >= 0; b++) {
+        auto &ln = h->lanes[(lane0 + b) % L];
+        PipeWs ws;
+        ws.coef = ln.coef.p; ws.cheb = ln.cheb.p; ws.spec_scratch = ln.spec.p; ws.work = ln.work.p; ws.scratch = &ln.scratch; ws.scratch_item_off = 0;
+        void *cov = (d_cov_out && d_cov_out[b]) ? d_cov_out[b] : ln.cov.p;
+        rc = run_ws(h, noutput_items, d_input_items + (size_t)b * N, cov, d_spectrum_out ? d_spectrum_out[b] : nullptr, d_max_out[b],
+                    d_argmax_out[b], ws, ln.st);
+    }
+    // the join happens whatever the enqueue loop returned: nothing may stay detached from the caller's stream
+    for (int u = 0; u < used && !detached; u++) {
+        auto &ln = h->lanes[(lane0 + u) % L];
+        const hipError_t e1 = hipEventRecord(ln.done, ln.st);
+        const hipError_t e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(caller, ln.done, 0) : e1;
+        if (e2 != hipSuccess && rc >= 0) { doa::set_error("music_pipeline_work_dev_batches: join failed: %s", hipGetErrorString(e2)); rc = DOA_ERR_HIP; }
+    }
+    return rc < 0 ? rc : n_batches * noutput_items;
+}
+
+int doa_music_pipeline_set_lane_streams(doa_music_pipeline_t *h, int n_lanes, void *const *hip_streams)
+{
+    doa::clear_error();
+    if (!h || n_lanes < 1 || n_lanes > doa_music_pipeline::kMaxLanes || !hip_streams) {
+        doa::set_error("music_pipeline_set_lane_streams: need 1 <= n_lanes <= %d and the streams", doa_music_pipeline::kMaxLanes);
+        return DOA_ERR_INVALID_ARG;
+    }
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
+    for (int l = 0; l < n_lanes; l++) {
+        auto &ln = h->lanes[l];
+        if (ln.st) { (void)hipStreamSynchronize(ln.st); if (ln.own_stream) (void)hipStreamDestroy(ln.st); }
+        ln.st = static_cast<hipStream_t>(hip_streams[l]);
+        ln.own_stream = false;
+    }
+    h->n_lanes = n_lanes;
+    h->next_lane = 0;
+    return DOA_OK;
+}
+
+int doa_music_pipeline_synchronize(doa_music_pipeline_t *h)
+{
+    doa::clear_error();
+    if (!h) { doa::set_error("music_pipeline_synchronize: bad arguments"); return DOA_ERR_INVALID_ARG; }
+    if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
+    for (int l = 0; l < doa_music_pipeline::kMaxLanes; l++)
+        if (h->lanes[l].st) DOA_HIP_TRY(hipStreamSynchronize(h->lanes[l].st));
+    return DOA_OK;
 }
 
 int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const void *const *input_items, void *cov_out,
@@ -329,6 +507,19 @@ int doa_music_pipeline_lanes_idle(doa_music_pipeline_t *h)
     for (auto st : h->hst)
         if (st && hipStreamQuery(st) != hipSuccess) return 0;
     return 1;
+}
+
+int doa_music_pipeline_set_internal_precision(doa_music_pipeline_t *h, int bits)
+{
+    doa::clear_error();
+    if (!h || (bits != 32 && bits != 64)) { doa::set_error("music_pipeline_set_internal_precision: need a handle and bits = 32 or 64"); return DOA_ERR_INVALID_ARG; }
+    if (doa::music_uses_cheb(h->N, bits)) {
+        if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
+        const int rc = h->d_cheb.reserve((size_t)h->max_batch * doa::kChebRecord * sizeof(double));
+        if (rc != DOA_OK) return rc;
+    }
+    h->bits = bits;
+    return DOA_OK;
 }
 
 }  // extern "C"

@@ -434,4 +434,12 @@ int doa_rootMUSIC_linear_array_select_debug(doa_rootMUSIC_linear_array_t *h, int
     return noutput_items;
 }
 
+int doa_rootMUSIC_linear_array_set_internal_precision(doa_rootMUSIC_linear_array_t *h, int bits)
+{
+    doa::clear_error();
+    if (!h || (bits != 32 && bits != 64)) { doa::set_error("rootMUSIC_linear_array_set_internal_precision: need a handle and bits = 32 or 64"); return DOA_ERR_INVALID_ARG; }
+    h->bits = bits;
+    return DOA_OK;
+}
+
 }  // extern "C"

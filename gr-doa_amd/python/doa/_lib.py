@@ -70,6 +70,11 @@ SIGNATURES = {
     "doa_autocorrelate_input_span": (C.c_longlong, [_vp, C.c_int]),
     "doa_autocorrelate_work": (C.c_int, [_vp, C.c_int, _vpp, _vp]),
     "doa_autocorrelate_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp]),
+    "doa_hip_evd_fallback_count": (C.c_longlong, [C.c_int]),
+    "doa_MUSIC_lin_array_set_internal_precision": (C.c_int, [_vp, C.c_int]),
+    "doa_rootMUSIC_linear_array_set_internal_precision": (C.c_int, [_vp, C.c_int]),
+    "doa_calibrate_lin_array_set_internal_precision": (C.c_int, [_vp, C.c_int]),
+    "doa_music_pipeline_set_internal_precision": (C.c_int, [_vp, C.c_int]),
     "doa_MUSIC_lin_array_create": (_vp, [C.c_float, C.c_int, C.c_int, C.c_int]),
     "doa_MUSIC_lin_array_destroy": (None, [_vp]),
     "doa_MUSIC_lin_array_work": (C.c_int, [_vp, C.c_int, _vp, _vp]),
@@ -103,6 +108,10 @@ SIGNATURES = {
     "doa_music_pipeline_set_stages": (C.c_int, [_vp, C.c_int]),
     "doa_music_pipeline_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp, _vp]),
     "doa_music_pipeline_work": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp]),
+    "doa_music_pipeline_work_dev_batches": (C.c_int, [_vp, C.c_int, C.c_int, _vpp, _vpp, _vpp, _vpp, _vpp, _vp]),
+    "doa_music_pipeline_set_lanes": (C.c_int, [_vp, C.c_int]),
+    "doa_music_pipeline_set_lane_streams": (C.c_int, [_vp, C.c_int, _vpp]),
+    "doa_music_pipeline_synchronize": (C.c_int, [_vp]),
     "doa_music_pipeline_inject_failure": (C.c_int, [_vp, C.c_int]),
     "doa_music_pipeline_lanes_idle": (C.c_int, [_vp]),
     "doa_compass_mean_create": (_vp, [C.c_int]),

@@ -31,10 +31,15 @@ def _vp(a: np.ndarray) -> C.c_void_p:
     return C.c_void_p(a.ctypes.data)
 
 
+DETACHED = "detached"      # work_dev_batches(..., stream=DETACHED): no ordering on any caller stream (DOA_STREAM_DETACHED)
+
+
 def _stream_ptr(stream) -> C.c_void_p:
-    """Accept None, an int (hipStream_t) or a torch.cuda.Stream."""
+    """Accept None, an int (hipStream_t), a torch.cuda.Stream or DETACHED."""
     if stream is None:
         return C.c_void_p(0)
+    if isinstance(stream, str) and stream == DETACHED:
+        return C.c_void_p(2 ** 64 - 1)
     if hasattr(stream, "cuda_stream"):
         return C.c_void_p(int(stream.cuda_stream))
     return C.c_void_p(int(stream))
@@ -56,6 +61,14 @@ class _Block:
             self.close()
         except Exception:
             pass
+
+    _set_precision = None
+
+    def set_internal_precision(self, bits: int) -> None:
+        """Per-handle internal precision of EVD / scan (32 or 64; include/doa_hip.h); blocks without an EVD have none."""
+        if type(self)._set_precision is None:
+            raise AttributeError(f"{type(self).__name__} has no internal precision")
+        check(type(self)._set_precision(self._h, int(bits)))
 
 
 class autocorrelate(_Block):
@@ -205,6 +218,7 @@ class MUSIC_lin_array(_Block):
     (reference lib/MUSIC_lin_array_impl.cc:47-87)."""
 
     _destroy = staticmethod(lib.doa_MUSIC_lin_array_destroy)
+    _set_precision = staticmethod(lib.doa_MUSIC_lin_array_set_internal_precision)
 
     def __init__(self, norm_spacing, num_targets, inputs, pspectrum_len):
         super().__init__()
@@ -276,6 +290,7 @@ class rootMUSIC_linear_array(_Block):
     (reference lib/rootMUSIC_linear_array_impl.cc:46-59)."""
 
     _destroy = staticmethod(lib.doa_rootMUSIC_linear_array_destroy)
+    _set_precision = staticmethod(lib.doa_rootMUSIC_linear_array_set_internal_precision)
 
     def __init__(self, norm_spacing, num_targets, inputs):
         super().__init__()
@@ -324,6 +339,7 @@ class calibrate_lin_array(_Block):
     complex in, vlen N complex out (reference lib/calibrate_lin_array_impl.cc:46-75)."""
 
     _destroy = staticmethod(lib.doa_calibrate_lin_array_destroy)
+    _set_precision = staticmethod(lib.doa_calibrate_lin_array_set_internal_precision)
 
     def __init__(self, norm_spacing, num_ant_ele, pilot_angle):
         super().__init__()
@@ -352,6 +368,7 @@ class music_pipeline(_Block):
     entry point the benchmark drives.  Not a block of the reference."""
 
     _destroy = staticmethod(lib.doa_music_pipeline_destroy)
+    _set_precision = staticmethod(lib.doa_music_pipeline_set_internal_precision)
 
     def __init__(self, inputs, snapshot_size, overlap_size, avg_method, norm_spacing, num_targets,
                  pspectrum_len, max_batch=4096):
@@ -406,6 +423,31 @@ class music_pipeline(_Block):
             self._h, int(noutput_items), ptr_array(d_input_ptrs), C.c_void_p(int(d_cov_ptr or 0)),
             C.c_void_p(int(d_spec_ptr or 0)), C.c_void_p(int(d_max_ptr)), C.c_void_p(int(d_argmax_ptr)),
             _stream_ptr(stream)))
+
+    def set_lanes(self, n_lanes: int) -> None:
+        check(lib.doa_music_pipeline_set_lanes(self._h, int(n_lanes)))
+
+    def set_lane_streams(self, streams) -> None:
+        """Lanes on streams the caller created (torch.cuda.Stream objects or hipStream_t values); the caller keeps them alive."""
+        self._lane_streams = list(streams)
+        check(lib.doa_music_pipeline_set_lane_streams(self._h, len(self._lane_streams),
+                                                      ptr_array([_stream_ptr(s).value or 0 for s in self._lane_streams])))
+
+    def synchronize(self) -> None:
+        """Host-side join of the lanes (after work_dev_batches(..., stream=doa.DETACHED))."""
+        check(lib.doa_music_pipeline_synchronize(self._h))
+
+    def work_dev_batches(self, noutput_items, d_input_ptrs, d_cov_ptrs, d_spec_ptrs, d_max_ptrs, d_argmax_ptrs, stream=None) -> int:
+        """n_batches = len(d_max_ptrs) batches in one call, overlapped over the handle's own lanes (doa_hip.h).
+        d_input_ptrs: n_batches lists of `inputs` device pointers (or one flat list); d_cov_ptrs / d_spec_ptrs: lists of
+        device pointers (0 = not wanted) or None."""
+        nb = len(d_max_ptrs)
+        flat = [p for b in d_input_ptrs for p in b] if nb and isinstance(d_input_ptrs[0], (list, tuple)) else list(d_input_ptrs)
+        assert len(flat) == nb * self.inputs and len(d_argmax_ptrs) == nb
+        opt = lambda ptrs: None if ptrs is None else ptr_array([int(p or 0) for p in ptrs])
+        return check(lib.doa_music_pipeline_work_dev_batches(
+            self._h, nb, int(noutput_items), ptr_array(flat), opt(d_cov_ptrs), opt(d_spec_ptrs), ptr_array(d_max_ptrs),
+            ptr_array(d_argmax_ptrs), _stream_ptr(stream)))
 
     def input_span(self, noutput_items) -> int:
         n = int(noutput_items)
@@ -516,3 +558,8 @@ def get_internal_precision() -> int:
 
 def device_count() -> int:
     return int(lib.doa_hip_device_count())
+
+
+def evd_fallback_count(reset: bool = False) -> int:
+    """Diagnostics: items whose eigendecomposition left the signal-subspace fast path for the Jacobi fall-back."""
+    return int(lib.doa_hip_evd_fallback_count(1 if reset else 0))

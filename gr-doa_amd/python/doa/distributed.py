@@ -89,6 +89,10 @@ def scatter_shards(streams, n_streams: int, n_snapshots: int, snapshot_size: int
     gloo = dist.get_backend() == "gloo"
     dev = torch.device("cpu") if gloo else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     me = shards[rank]
+    # every rank enters one collective first: on RCCL a FIRST point-to-point batch in which not all ranks take part (a rank
+    # whose shard is empty posts nothing below) is undefined behaviour; after a collective the communicator is up on all of them
+    sync = torch.zeros(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(sync)
     if rank == src:
         if streams is None or len(streams) != n_streams:
             raise ValueError("the ingest rank must hold all n_streams streams")

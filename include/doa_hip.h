@@ -88,6 +88,10 @@ DOA_HIP_API size_t doa_stream_stride_bytes(size_t stream_bytes);
  * Returns DOA_OK or DOA_ERR_INVALID_ARG. */
 DOA_HIP_API int doa_set_internal_precision(int bits);
 DOA_HIP_API int doa_get_internal_precision(void);
+/* The call above only sets the process-wide DEFAULT a handle copies when it is created (two threads that want handles of
+ * different precisions would race on it); the precision is a property of the HANDLE and can be set on it directly, at
+ * any time between two work calls: doa_X_set_internal_precision(h, 32 | 64) for the four handle types that run the
+ * eigendecomposition (declared with their blocks below). */
 
 /* ---------------------------------------------------------------------------------------------
  * autocorrelate — gr::doa::autocorrelate::make(inputs, snapshot_size, overlap_size, avg_method)
@@ -143,9 +147,17 @@ DOA_HIP_API int doa_MUSIC_lin_array_work_dev(doa_MUSIC_lin_array_t *h, int noutp
 DOA_HIP_API int doa_MUSIC_lin_array_debug(doa_MUSIC_lin_array_t *h, int noutput_items,
                                           const void *input_items0, void *projector_out,
                                           void *null_spectrum_out);
+/* Diagnostics for tests: for 4 < num_ant_ele <= 16 and num_targets <= 4 (2 num_targets <= num_ant_ele), internal
+ * precision 64, the noise projector of MUSIC / Root-MUSIC / music_pipeline handles is computed from the SIGNAL subspace
+ * (shifted orthogonal iteration, every result checked by its residual and by a certificate that the subspace found is the
+ * one of the num_targets largest eigenvalues), and an item that fails any check takes the full Jacobi
+ * eigendecomposition instead.  This returns how many items took that fall-back since the last reset (process-wide, all
+ * handles; synchronises the device), or -1 without a device. */
+DOA_HIP_API long long doa_hip_evd_fallback_count(int reset);
 /* Items processed so far — the counter the reference prints from its destructor
  * (lib/MUSIC_lin_array_impl.cc:92-95,146). */
 DOA_HIP_API long long doa_MUSIC_lin_array_items_total(const doa_MUSIC_lin_array_t *h);
+DOA_HIP_API int doa_MUSIC_lin_array_set_internal_precision(doa_MUSIC_lin_array_t *h, int bits);
 
 /* ---------------------------------------------------------------------------------------------
  * find_local_max — gr::doa::find_local_max::make(num_max_vals, vector_len, x_min, x_max)
@@ -202,6 +214,7 @@ DOA_HIP_API int doa_rootMUSIC_linear_array_select_debug(doa_rootMUSIC_linear_arr
 DOA_HIP_API int doa_rootMUSIC_linear_array_work_dev(doa_rootMUSIC_linear_array_t *h,
                                                     int noutput_items, const void *d_input_items0,
                                                     void *d_output_items0, void *hip_stream);
+DOA_HIP_API int doa_rootMUSIC_linear_array_set_internal_precision(doa_rootMUSIC_linear_array_t *h, int bits);
 
 /* ---------------------------------------------------------------------------------------------
  * antenna_correction — gr::doa::antenna_correction::make(num_ant_ele, config_filename)
@@ -251,6 +264,7 @@ DOA_HIP_API int doa_calibrate_lin_array_work(doa_calibrate_lin_array_t *h, int n
 DOA_HIP_API int doa_calibrate_lin_array_work_dev(doa_calibrate_lin_array_t *h, int noutput_items,
                                                  const void *d_input_items0, void *d_output_items0,
                                                  void *hip_stream);
+DOA_HIP_API int doa_calibrate_lin_array_set_internal_precision(doa_calibrate_lin_array_t *h, int bits);
 
 /* ---------------------------------------------------------------------------------------------
  * music_pipeline — autocorrelate -> MUSIC_lin_array -> find_local_max(num_targets, pspectrum_len,
@@ -276,6 +290,41 @@ DOA_HIP_API int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput
                                             const void *const *d_input_items, void *d_cov_out,
                                             void *d_spectrum_out, void *d_max_out,
                                             void *d_argmax_out, void *hip_stream);
+/* n_batches independent batches of noutput_items snapshots each (<= max_batch) in ONE call, overlapped by the library:
+ * batch b runs its K1 -> EVD -> scan chain on one of the handle's own LANES (a HIP stream plus a private workspace; 4
+ * by default, rotating from call to call), so that the HBM-bound covariance kernel of one batch runs beside the
+ * issue-bound EVD / scan kernels of its neighbours -- the overlap a caller otherwise has to build from several handles on
+ * several streams of its own (reference work being chained: lib/autocorrelate_impl.cc:83-118 ->
+ * lib/MUSIC_lin_array_impl.cc:121-142 -> lib/find_local_max_impl.cc:167-194, wiring
+ * apps/run_MUSIC_lin_array_simulation.grc:1099-1370).  Results are bit-identical to n_batches work_dev calls.
+ *   d_input_items   HOST array of n_batches * inputs DEVICE pointers (batch b: entries b*inputs .. b*inputs+inputs-1)
+ *   d_cov_out, d_spectrum_out  HOST arrays of n_batches DEVICE pointers; the array or single entries may be NULL (no
+ *                   covariance copy wanted / angles-only mode for that batch, as in work_dev)
+ *   d_max_out, d_argmax_out    HOST arrays of n_batches DEVICE pointers (required)
+ *   hip_stream      a hipStream_t: the call is asynchronous like work_dev and ordered on that stream AS A WHOLE -- every lane
+ *                   it uses starts behind the work the stream held at the call (one event) and the stream continues behind
+ *                   the last batch of every lane (one event per lane): one fork and one join per call whatever n_batches
+ *                   is.  Or DOA_STREAM_DETACHED: no ordering against any caller stream (the inputs must be complete when
+ *                   the call is made); the caller joins with doa_music_pipeline_synchronize before it touches the
+ *                   outputs.  Cross-stream events cost tens of microseconds on this runtime: callers
+ *                   that submit many short calls want the detached form.
+ * Returns n_batches * noutput_items or a negative doa_status; after an error the join has still been enqueued. */
+#define DOA_STREAM_DETACHED ((void *)(size_t)-1)
+DOA_HIP_API int doa_music_pipeline_work_dev_batches(doa_music_pipeline_t *h, int n_batches, int noutput_items,
+                                                    const void *const *d_input_items, void *const *d_cov_out,
+                                                    void *const *d_spectrum_out, void *const *d_max_out,
+                                                    void *const *d_argmax_out, void *hip_stream);
+/* Host-side join: returns when every lane of the handle has finished what work_dev_batches gave it. */
+DOA_HIP_API int doa_music_pipeline_synchronize(doa_music_pipeline_t *h);
+/* Number of lanes work_dev_batches spreads its batches over (1..8, default 4; 1 = everything on hip_stream itself). */
+DOA_HIP_API int doa_music_pipeline_set_lanes(doa_music_pipeline_t *h, int n_lanes);
+/* Lanes on streams the CALLER created (n_lanes hipStream_t; they stay the caller's, the handle only uses them).  For a
+ * host program that draws its streams from a pool of its own (PyTorch, a GNU Radio buffer manager): HIP maps streams
+ * onto a few hardware queues in creation order, and which streams share a queue with which decides how well kernels of
+ * different lanes overlap (measured: 26 against 33 us per 4096-snapshot step for four lanes on one set of streams or
+ * another) -- the program that owns the process's streams is the one that can choose. */
+DOA_HIP_API int doa_music_pipeline_set_lane_streams(doa_music_pipeline_t *h, int n_lanes, void *const *hip_streams);
+DOA_HIP_API int doa_music_pipeline_set_internal_precision(doa_music_pipeline_t *h, int bits);
 /* Profiling aid: which stages later work_dev calls on this handle launch (bit 0 = K1 covariance, bit 1 = K2+K3
  * EVD, bit 2 = K4+K5 scan + peak pick; default 7).  A dropped stage leaves its outputs as the previous call
  * wrote them, so a profiler can time one kernel on valid intermediates; not for production use. */

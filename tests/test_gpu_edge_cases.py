@@ -105,3 +105,34 @@ def test_find_local_max_ties_and_flats_at_chunk_borders():
         blk.work(v.shape[0], [v], [o0, o1])
         r0, r1 = oracle.find_local_max(v, M, L, 0.0, 180.0)
         assert np.array_equal(o0, r0) and np.array_equal(o1, r1)
+
+
+def test_internal_precision_is_a_property_of_the_handle():
+    """the process-wide doa_set_internal_precision is only the default a handle copies at create; a handle's
+    own setter changes that handle and nothing else (two handles of different precisions side by side)."""
+    import doa_oracle as oracle
+    from scenarios import make_input
+    c, x = make_input("bench_cfg2")
+    R = oracle.autocorrelate(x, c["K"], c["ovl"], c["fb"], c["n"])
+    a = doa.MUSIC_lin_array(c["d"], c["M"], c["N"], c["P"])
+    b = doa.MUSIC_lin_array(c["d"], c["M"], c["N"], c["P"])
+    b.set_internal_precision(32)
+    assert doa.get_internal_precision() == 64                        # the default is untouched
+    sa, sb, sa2 = (np.empty((c["n"], c["P"]), np.float32) for _ in range(3))
+    a.work(c["n"], [R], [sa]); b.work(c["n"], [R], [sb])
+    assert not np.array_equal(sa, sb) and np.abs(sa - sb).max() < 0.5  # two arithmetic paths, same spectrum shape
+    b.set_internal_precision(64)
+    b.work(c["n"], [R], [sa2])
+    assert np.array_equal(sa, sa2)
+    with pytest.raises(doa.DoaError):
+        a.set_internal_precision(16)
+    pipe = doa.music_pipeline(c["N"], c["K"], c["ovl"], c["fb"], c["d"], c["M"], c["P"], max_batch=c["n"])
+    pipe.set_internal_precision(32)
+    pipe.set_internal_precision(64)                                  # back to the parity configuration (records re-reserved)
+    mx, am = np.empty((c["n"], c["M"]), np.float32), np.empty((c["n"], c["M"]), np.float32)
+    sp = np.empty((c["n"], c["P"]), np.float32)
+    assert pipe.work(c["n"], [x[k] for k in range(c["N"])], mx, am, spectrum_out=sp) == c["n"]
+    fresh = doa.music_pipeline(c["N"], c["K"], c["ovl"], c["fb"], c["d"], c["M"], c["P"], max_batch=c["n"])
+    mx2, am2, sp2 = np.empty_like(mx), np.empty_like(am), np.empty_like(sp)
+    assert fresh.work(c["n"], [x[k] for k in range(c["N"])], mx2, am2, spectrum_out=sp2) == c["n"]
+    assert np.array_equal(sp, sp2) and np.array_equal(am, am2)

@@ -267,3 +267,114 @@ def test_host_entry_short_snapshot_long_spectrum_takes_the_chunked_path():
     mx_s, am_s, spec_s = np.empty((m, M), np.float32), np.empty((m, M), np.float32), np.empty((m, P), np.float32)
     assert pipe.work(m, [x[k][:m * K] for k in range(N)], mx_s, am_s, spectrum_out=spec_s) == m
     assert np.array_equal(spec_s, spec[:m]) and np.array_equal(am_s, am[:m]) and np.array_equal(mx_s, mx[:m])
+
+
+@pytest.mark.parametrize("name,lanes", [("bench_cfg2", 4), ("grc_music_sim", 3), ("bench_cfg4", 2), ("five_ant", 4), ("bench_cfg2", 1)])
+def test_batches_entry_equals_single_calls_bit_for_bit(name, lanes):
+    """doa_music_pipeline_work_dev_batches -- K batches in one call, overlapped over the handle's own lanes,
+    one fork and one join on the caller's stream -- gives exactly the bits of K work_dev calls (same kernels, same
+    launch shapes), whatever mix of optional outputs the batches ask for."""
+    c, x = make_input(name)
+    N, M, P, n = c["N"], c["M"], c["P"], c["n"]
+    nb = 7
+    S = c["K"] - c["ovl"]
+    span = (n - 1) * S + c["K"]
+    rng = np.random.default_rng(3)
+    # batch b = the scenario's streams with a different scale and noise added: distinct inputs per batch
+    xs = [(x * np.float32(1.0 + 0.25 * b) + (0.02 * (rng.standard_normal(x.shape) + 1j * rng.standard_normal(x.shape))).astype(np.complex64)).astype(np.complex64)
+          for b in range(nb)]
+    d_in = [[_dev(xb[k][:span]) for k in range(N)] for xb in xs]
+    mk = lambda shape, dt: [torch.full(shape, -3.0 if dt != torch.complex64 else 0, dtype=dt, device="cuda") for _ in range(nb)]
+    ref = dict(cov=mk((n, N * N), torch.complex64), spec=mk((n, P), torch.float32), mx=mk((n, M), torch.float32), am=mk((n, M), torch.float32))
+    got = dict(cov=mk((n, N * N), torch.complex64), spec=mk((n, P), torch.float32), mx=mk((n, M), torch.float32), am=mk((n, M), torch.float32))
+    one = doa.music_pipeline(N, c["K"], c["ovl"], c["fb"], c["d"], M, P, max_batch=n)
+    st = torch.cuda.current_stream()
+    # optional outputs per batch: covariance wanted for even batches, spectrum for all but batch 2 and 5
+    want_cov = [b % 2 == 0 for b in range(nb)]
+    want_spec = [b not in (2, 5) for b in range(nb)]
+    for b in range(nb):
+        one.work_dev(n, [t.data_ptr() for t in d_in[b]], ref["cov"][b].data_ptr() if want_cov[b] else 0,
+                     ref["spec"][b].data_ptr() if want_spec[b] else 0, ref["mx"][b].data_ptr(), ref["am"][b].data_ptr(), st)
+    torch.cuda.synchronize()
+    pipe = doa.music_pipeline(N, c["K"], c["ovl"], c["fb"], c["d"], M, P, max_batch=n)
+    pipe.set_lanes(lanes)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        # the fork must order the lanes behind what the caller's stream holds: refresh batch 0's inputs ON that stream right
+        # before the call, and read batch nb-1's result on it right after (the join)
+        fresh = [t.clone() for t in d_in[0]]
+        for t in d_in[0]:
+            t.zero_()
+        torch.cuda._sleep(2_000_000)
+        for t, f in zip(d_in[0], fresh):
+            t.copy_(f)
+        produced = pipe.work_dev_batches(n, [[t.data_ptr() for t in d_in[b]] for b in range(nb)],
+                                         [got["cov"][b].data_ptr() if want_cov[b] else 0 for b in range(nb)],
+                                         [got["spec"][b].data_ptr() if want_spec[b] else 0 for b in range(nb)],
+                                         [t.data_ptr() for t in got["mx"]], [t.data_ptr() for t in got["am"]], side)
+        last = got["am"][nb - 1].clone()
+    assert produced == nb * n
+    side.synchronize()
+    assert torch.equal(last, ref["am"][nb - 1])
+    torch.cuda.synchronize()
+    for b in range(nb):
+        assert torch.equal(got["mx"][b], ref["mx"][b]) and torch.equal(got["am"][b], ref["am"][b]), b
+        if want_cov[b]:
+            assert torch.equal(torch.view_as_real(got["cov"][b]), torch.view_as_real(ref["cov"][b])), b
+        if want_spec[b]:
+            assert torch.equal(got["spec"][b], ref["spec"][b]), b
+        else:
+            assert bool((got["spec"][b] == -3.0).all())                 # angles-only batches leave the caller's buffer alone
+    # whole arrays omitted: angles only, no covariance copies
+    am2 = [torch.empty((n, M), dtype=torch.float32, device="cuda") for _ in range(nb)]
+    mx2 = [torch.empty((n, M), dtype=torch.float32, device="cuda") for _ in range(nb)]
+    assert pipe.work_dev_batches(n, [[t.data_ptr() for t in d_in[b]] for b in range(nb)], None, None, [t.data_ptr() for t in mx2],
+                                 [t.data_ptr() for t in am2], st) == nb * n
+    torch.cuda.synchronize()
+    for b in range(nb):
+        assert torch.equal(am2[b], ref["am"][b]) and torch.equal(mx2[b], ref["mx"][b]), b
+
+
+def test_batches_entry_argument_checks():
+    pipe = doa.music_pipeline(4, 64, 0, 0, 0.5, 1, 256, max_batch=8)
+    z = torch.zeros(8 * 64, dtype=torch.complex64, device="cuda")
+    o = torch.empty((8, 1), dtype=torch.float32, device="cuda")
+    ins = [[z.data_ptr()] * 4]
+    with pytest.raises(doa.DoaError):
+        pipe.work_dev_batches(9, ins, None, None, [o.data_ptr()], [o.data_ptr()])          # > max_batch
+    with pytest.raises(doa.DoaError):
+        pipe.work_dev_batches(8, ins, None, None, [0], [o.data_ptr()])                     # missing peak output
+    with pytest.raises(doa.DoaError):
+        pipe.set_lanes(0)
+    assert pipe.work_dev_batches(0, ins, None, None, [o.data_ptr()], [o.data_ptr()]) == 0
+
+
+def test_batches_entry_detached_and_adopted_streams():
+    """The detached form (no ordering on a caller stream, joined by doa_music_pipeline_synchronize) and lanes on
+    caller-created streams give the same bits as single calls; lanes keep rotating from call to call."""
+    c, x = make_input("bench_cfg2")
+    N, M, P, n = c["N"], c["M"], c["P"], c["n"]
+    nb = 6
+    d_in = [[_dev(x[k] * np.float32(1.0 + 0.125 * b)) for k in range(N)] for b in range(nb)]
+    one = doa.music_pipeline(N, c["K"], c["ovl"], c["fb"], c["d"], M, P, max_batch=n)
+    ref_am, ref_sp = [], []
+    for b in range(nb):
+        am = torch.empty((n, M), dtype=torch.float32, device="cuda"); mx = torch.empty_like(am)
+        sp = torch.empty((n, P), dtype=torch.float32, device="cuda")
+        one.work_dev(n, [t.data_ptr() for t in d_in[b]], 0, sp.data_ptr(), mx.data_ptr(), am.data_ptr(), torch.cuda.current_stream())
+        ref_am.append(am); ref_sp.append(sp)
+    torch.cuda.synchronize()
+    for adopt in (False, True):
+        pipe = doa.music_pipeline(N, c["K"], c["ovl"], c["fb"], c["d"], M, P, max_batch=n)
+        if adopt:
+            pipe.set_lane_streams([torch.cuda.Stream() for _ in range(3)])
+        am = [torch.empty((n, M), dtype=torch.float32, device="cuda") for _ in range(nb)]
+        mx = [torch.empty((n, M), dtype=torch.float32, device="cuda") for _ in range(nb)]
+        sp = [torch.empty((n, P), dtype=torch.float32, device="cuda") for _ in range(nb)]
+        for b0, b1 in ((0, 1), (1, 4), (4, 6)):                      # calls of 1, 3 and 2 batches: the rotation carries over
+            assert pipe.work_dev_batches(n, [[t.data_ptr() for t in d_in[b]] for b in range(b0, b1)], None,
+                                         [sp[b].data_ptr() for b in range(b0, b1)], [mx[b].data_ptr() for b in range(b0, b1)],
+                                         [am[b].data_ptr() for b in range(b0, b1)], doa.DETACHED) == (b1 - b0) * n
+        pipe.synchronize()
+        for b in range(nb):
+            assert torch.equal(am[b], ref_am[b]) and torch.equal(sp[b], ref_sp[b]), (adopt, b)

@@ -184,8 +184,8 @@ def _select_cases(N, M, d, rng):
         out.append(z[::-1].copy())
     # (c) equal distances: index_min takes the first such root in the list's order (:133); radii exact in binary
     for r in (0.5, 0.75):
-        k = min(D, M + 2)
-        z = np.concatenate([r * np.array([1.0, 1j, -1.0, -1j, 1.0, 1j])[:k] * 1.0, rng.uniform(1.5, 2.5, D - k) * ph(D - k)])
+        k = min(D, M + 2, 4)                          # 1, j, -1, -j: the four phases whose modulus is exact
+        z = np.concatenate([r * np.array([1.0, 1j, -1.0, -1j])[:k], rng.uniform(1.5, 2.5, D - k) * ph(D - k)])
         out.append(z)
         out.append(np.roll(z, 1))
     # (d) angles outside the visible region (|arg z| > 2 pi d): acos(> 1) = NaN, sorted last

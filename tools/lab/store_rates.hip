@@ -63,6 +63,27 @@ __global__ __launch_bounds__(256) void store_rot_kernel(float *__restrict__ out,
         }
     }
 }
+// a wave takes 16 consecutive rows in 16 consecutive turns (item = (k >> 4) 16 n_waves + 16 w + (k & 15))
+template <int FLAV>
+__global__ __launch_bounds__(256) void store_blk16_kernel(float *__restrict__ out, int n_items, float v)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * 4;
+    const int turns = 16 * ((n_items + 16 * n_waves - 1) / (16 * n_waves));
+    for (int k = 0; k < turns; k++) {
+        const int item = (k >> 4) * (16 * n_waves) + 16 * wave + (k & 15);
+        if (item >= n_items) continue;
+        float *row = out + (size_t)item * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 t = {v + j, v, v, v + lane};
+            f4 *p = reinterpret_cast<f4 *>(row + 4 * lane + 256 * j);
+            if constexpr (FLAV == 0) *p = t; else __builtin_nontemporal_store(t, p);
+        }
+    }
+}
 // what a fill kernel does: thread t writes 16 B at t, t + T, t + 2T, ... (every wave instruction 1 KiB contiguous, the whole
 // grid a contiguous moving window)
 template <int FLAV>
@@ -130,7 +151,11 @@ int main(int argc, char **argv)
         time_it("linear fill, nt", wpc, n_items, [&](int r) { hipLaunchKernelGGL(store_linear_kernel<1>, dim3(cus * wpc / 4), dim3(256), 0, 0, bufs[r & 1], (size_t)n_items * 256, 1.0f); });
         time_it("linear fill, plain", wpc, n_items, [&](int r) { hipLaunchKernelGGL(store_linear_kernel<0>, dim3(cus * wpc / 4), dim3(256), 0, 0, bufs[r & 1], (size_t)n_items * 256, 1.0f); });
     }
-    for (int rot : {0, 1, 5, 37, 129, 1001})
+    for (int wpc : {4, 8, 12, 16, 20}) {
+        time_it("nt rows, 16 consecutive per wave", wpc, n_items, [&](int r) { hipLaunchKernelGGL(store_blk16_kernel<1>, dim3(cus * wpc / 4), dim3(256), 0, 0, bufs[r & 1], n_items, 1.0f); });
+        time_it("plain rows, 16 consecutive per wave", wpc, n_items, [&](int r) { hipLaunchKernelGGL(store_blk16_kernel<0>, dim3(cus * wpc / 4), dim3(256), 0, 0, bufs[r & 1], n_items, 1.0f); });
+    }
+    for (int rot : {0})
         for (int wpc : {6, 8, 10, 12, 14, 16, 20}) {
             char nm[64]; snprintf(nm, sizeof nm, "nt rows, rotation %d", rot);
             time_it(nm, wpc, n_items, [&](int r) { hipLaunchKernelGGL(store_rot_kernel<1>, dim3(cus * wpc / 4), dim3(256), 0, 0, bufs[r & 1], n_items, 1.0f, rot); });
