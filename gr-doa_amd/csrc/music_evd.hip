@@ -16,15 +16,34 @@
 
 namespace doa {
 
+}  // namespace doa
+#include "evd_subspace.hpp"
+namespace doa {
+
 template <int N, typename T>
 __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
                                                        double *__restrict__ coef_d, float2 *__restrict__ pn_out,
-                                                       int n_items, int M, double *__restrict__ cheb_d)
+                                                       int n_items, int M, double *__restrict__ cheb_d,
+                                                       int *__restrict__ fallback_count)
 {
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= n_items) return;
     T u[2 * N];
-    evd_item_coefficients<N, T>(R + (size_t)item * (N * N), M, u, pn_out ? pn_out + (size_t)item * (N * N) : nullptr);
+    const float2 *Ri = R + (size_t)item * (N * N);
+    float2 *pn_i = pn_out ? pn_out + (size_t)item * (N * N) : nullptr;
+    // double: the signal-subspace iteration first (evd_subspace.hpp, one lane per item); the lanes it does not certify run the
+    // cyclic Jacobi below (the whole wave skips it when every lane is done)
+    // -- for ONE source only: with one lane per item a wave runs as long as its slowest lane, and with two or three sources
+    // the spread of step counts over 64 items (median 4-6, some 11-15, a few fall-backs) costs more than it saves: measured
+    // 11.9 against 10.8 us per 4096 items at M = 2 (configs[2]) and 30 against 10.4 us on the simulation flowgraph's shape
+    bool done = false;
+    if constexpr (sizeof(T) == 8) {
+        if (M == 1) {
+            done = evd_small_subspace<N, 1>(Ri, u, pn_i);
+            if (!done && fallback_count) atomicAdd(fallback_count, 1);
+        }
+    }
+    if (!done) evd_item_coefficients<N, T>(Ri, M, u, pn_i);
     // float record for the float scan; double record for the root finder (Root-MUSIC's near-double roots amplify
     // a float rounding of u_l by ~1e3-1e4) and for the double scan
     if (coef) {
@@ -598,10 +617,6 @@ __global__ __launch_bounds__(64) void music_evd_block16_kernel(const float2 *__r
     evd_block16_item<T, LEAN>(R + (size_t)item * (N * N), item, coef, coef_d, pn_out, N, M, pilot, cal_out, sVr, sVi, sLam);
 }
 
-}  // namespace doa
-#include "evd_subspace.hpp"
-namespace doa {
-
 // One wave per item: the signal-subspace iteration (evd_subspace.hpp) first; whatever it does not certify takes the
 // block Jacobi above on the same wave.  G = 8 (N <= 8) / 16, MC = num_targets (1..4); double only.
 template <int G, int MC, bool PN>
@@ -704,10 +719,10 @@ template <int N> static void launch_evd_n(int M, int n_items, const void *d_R, v
     dim3 block(64), grid((n_items + 63) / 64);
     if (bits == 32)
         hipLaunchKernelGGL((music_evd_kernel<N, float>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,
-                           (double *)d_coef_d, (float2 *)d_pn, n_items, M, (double *)nullptr);
+                           (double *)d_coef_d, (float2 *)d_pn, n_items, M, (double *)nullptr, (int *)nullptr);
     else
         hipLaunchKernelGGL((music_evd_kernel<N, double>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,
-                           (double *)d_coef_d, (float2 *)d_pn, n_items, M, (double *)d_cheb);
+                           (double *)d_coef_d, (float2 *)d_pn, n_items, M, (double *)d_cheb, evd_fallback_counter());
 }
 
 int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,

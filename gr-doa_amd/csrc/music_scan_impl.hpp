@@ -333,9 +333,9 @@ __device__ __forceinline__ void lean_scan_item(const T (&c)[LeanRecord<N, T>::kL
     if constexpr (ABL == 2) {
 #pragma unroll
         for (int j = 0; j < CH; j++)
-            store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4((float)c[0], (float)j, -1.f, -2.f));
+            store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4((float)lane, (float)j, -1.f, -2.f));
         if (lane == 0) { pk_val_item[0] = 0.0f; pk_loc_item[0] = xs[lane]; }
-        return;
+        return;                 // (nothing here depends on the item's record: the loop's scalar loads are never waited for)
     }
     // pass 1: the null spectrum itself (no reciprocal), the minimum of each lane's 4-angle groups, the item minimum
     float qf[CH][4], cm[CH];
@@ -472,15 +472,11 @@ __device__ __forceinline__ void lean_load_table(const T *__restrict__ ztab, int 
         for (int e = 0; e < 4; e++) asm volatile("" :: "v"(zr[j][e]), "v"(zi[j][e]));
 }
 
-// item_shift: 0 = wave w takes items w, w + n_waves, ... (every wave the same count at the benchmark batch); 4 = a wave
-// takes SIXTEEN consecutive items per turn of the grid (item = (k >> 4) 16 n_waves + 16 w + (k & 15)): at large batches the
-// rows a wave writes are then one 64 KiB run instead of 4 KiB every n_waves rows (measured, stores alone: 188-196 us
-// against 213-219 us per 262144 rows of 4 KiB).
 template <int N, int CH, typename T, bool MULTI = false, bool PEAKS = true, bool STORE = true, int ABL = 0>
 __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                                float *__restrict__ spec, int n_items,
                                                                const float *__restrict__ xaxis, float *__restrict__ pk_val,
-                                                               float *__restrict__ pk_loc, int M, int item_shift, int prefetch2)
+                                                               float *__restrict__ pk_loc, int M)
 {
     constexpr int P = 256 * CH;
     constexpr int RL = LeanRecord<N, T>::kLen;
@@ -494,35 +490,23 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
     const int n_waves = gridDim.x * (blockDim.x / kWave);
     T zr[CH][4], zi[CH][4];
     lean_load_table<CH, T>(ztab, lane, zr, zi);
-    const int sub_mask = (1 << item_shift) - 1;
-    auto item_of = [&](int k) { return (k >> item_shift) * (n_waves << item_shift) + (wave << item_shift) + (k & sub_mask); };
-    const int per_turn = n_waves << item_shift;
-    const int turns = ((n_items + per_turn - 1) / per_turn) << item_shift;
-    // coefficient records arrive through scalar loads, requested TWO items ahead: under a write-saturated memory system a
-    // read takes longer than one item's arithmetic (DOA_SCAN_PREFETCH=1 in lab builds: one item ahead, the round-2 form)
-    T c[RL], c_n1[RL], c_n2[RL];
-    auto fetch = [&](int k, T (&dst)[RL]) {
-        const int it = item_of(k);
-        if (k < turns && it < n_items) {
+    // coefficient records arrive through scalar loads; the next item's record is requested before this item's
+    // arithmetic so that its latency hides behind it (two items ahead measured no better: 231 against 219-227 us per
+    // 262144 items; neither did sixteen consecutive items per wave and turn)
+    T c[RL], c_next[RL];
+    if (wave < n_items) {
 #pragma unroll
-            for (int i = 0; i < RL; i++) dst[i] = coef[(size_t)it * RL + i];
+        for (int k = 0; k < RL; k++) c_next[k] = coef[(size_t)wave * RL + k];
+    }
+    for (int item = wave; item < n_items; item += n_waves) {
+#pragma unroll
+        for (int i = 0; i < RL; i++) c[i] = c_next[i];
+        const int nxt = item + n_waves;
+        if (nxt < n_items) {
+#pragma unroll
+            for (int i = 0; i < RL; i++) c_next[i] = coef[(size_t)nxt * RL + i];
         }
-    };
-    fetch(0, c_n1);
-    if (prefetch2) fetch(1, c_n2);
-    for (int k = 0; k < turns; k++) {
-        const int item = item_of(k);
-#pragma unroll
-        for (int i = 0; i < RL; i++) c[i] = c_n1[i];
-        if (prefetch2) {
-#pragma unroll
-            for (int i = 0; i < RL; i++) c_n1[i] = c_n2[i];
-            fetch(k + 2, c_n2);
-        } else {
-            fetch(k + 1, c_n1);
-        }
-        if (item < n_items)
-            lean_scan_item<N, CH, T, MULTI, PEAKS, STORE, ABL>(c, zr, zi, ztab, spec + (size_t)item * P, xs, pk_val + (size_t)item * M,
+        lean_scan_item<N, CH, T, MULTI, PEAKS, STORE, ABL>(c, zr, zi, ztab, spec + (size_t)item * P, xs, pk_val + (size_t)item * M,
                                                           pk_loc + (size_t)item * M, M, lane);
     }
 }
@@ -769,13 +753,14 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
     if (aligned && !q && n_ant == N && (P == 256 || P == 512 || P == 1024) && (!kPre || pk.cheb)) {
         const T *rec = kPre ? static_cast<const T *>(pk.cheb) : co;
         int lb = (n_items + waves_per_block - 1) / waves_per_block;
-        // Waves per CU.  Alone at large batches the kernel runs within a few per cent of the rate its row stores reach on
-        // their own, and what that rate is depends on how many waves store at once (tools/lab/store_rates.hip: 4 KiB rows
-        // from 8 / 12 / 16 waves per CU: 203 / 180 / 214 us per GiB).
-        const int lwpc = DOA_LAB_ENV_INT("DOA_SCAN_LEAN_WAVES_PER_CU", 12);
+        // Waves per CU: 12 up to a few items per wave (the benchmark batch: 2048 waves with two items each; one item per wave
+        // makes every wave pay the 16 KiB table load for 4 KiB of output), 16 -- all the 104-VGPR kernel can hold -- beyond:
+        // at large batches the kernel sits between its two ablations (rows stored without arithmetic, arithmetic without
+        // stores: DESIGN.md section 3) and a fourth wave per SIMD is worth 225-229 against 232-240 us per 262144 items.
+        const int per_wave16 = n_items / (cu_count() * 16);
+        const int lwpc_env = DOA_LAB_ENV_INT("DOA_SCAN_LEAN_WAVES_PER_CU", 0);
+        const int lwpc = lwpc_env > 0 ? lwpc_env : (per_wave16 >= 4 ? 16 : 12);
         const int cap = cu_count() * lwpc / waves_per_block;
-        int item_shift = 0;
-        const int prefetch2 = DOA_LAB_ENV_INT("DOA_SCAN_PREFETCH", 2) >= 2;
         if (lb > cap) {
             // every wave takes the same number of items (4096 items on a cap of 3072 waves would be one round of 3072 and a
             // second of 1024 with two thirds of the chip idle: 2048 waves with two items each instead)
@@ -783,15 +768,11 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
             const int per_wave = (n_items + cap_waves - 1) / cap_waves;
             const int waves = (n_items + per_wave - 1) / per_wave;
             lb = (waves + waves_per_block - 1) / waves_per_block;
-            // sixteen consecutive items per wave and turn once every wave has at least two such runs to do
-            const int shift_env = DOA_LAB_ENV_INT("DOA_SCAN_ITEM_SHIFT", -1);
-            if (per_wave >= 32) { lb = cap; item_shift = 4; }
-            if (shift_env >= 0) { item_shift = shift_env; if (shift_env == 0) lb = (waves + waves_per_block - 1) / waves_per_block; else lb = cap; }
         }
         dim3 lgrid(lb);
 #define DOA_LEAN_LAUNCH(CH_, MULTI_, PEAKS_, STORE_)                                                               \
     hipLaunchKernelGGL((music_scan_peak1_kernel<N, CH_, T, MULTI_, PEAKS_, STORE_>), lgrid, block, 0, st, rec, z, sp,   \
-                       n_items, pk.xaxis, pk.val, pk.loc, pk.M, item_shift, prefetch2)
+                       n_items, pk.xaxis, pk.val, pk.loc, pk.M)
 #define DOA_LEAN_CH(MULTI_, PEAKS_, STORE_)                                                                        \
     do {                                                                                                           \
         if (P == 256) DOA_LEAN_LAUNCH(1, MULTI_, PEAKS_, STORE_);                                                  \
@@ -805,10 +786,10 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
             if (ablate && P == 1024 && pk.val && pk.store && pk.M == 1) {
                 if (ablate == 1)
                     hipLaunchKernelGGL((music_scan_peak1_kernel<4, 4, T, false, true, true, 1>), lgrid, block, 0, st, rec, z, sp, n_items,
-                                       pk.xaxis, pk.val, pk.loc, pk.M, item_shift, prefetch2);
+                                       pk.xaxis, pk.val, pk.loc, pk.M);
                 else
                     hipLaunchKernelGGL((music_scan_peak1_kernel<4, 4, T, false, true, true, 2>), lgrid, block, 0, st, rec, z, sp, n_items,
-                                       pk.xaxis, pk.val, pk.loc, pk.M, item_shift, prefetch2);
+                                       pk.xaxis, pk.val, pk.loc, pk.M);
                 return true;
             }
         }

@@ -441,13 +441,19 @@ class music_pipeline(_Block):
         """n_batches = len(d_max_ptrs) batches in one call, overlapped over the handle's own lanes (doa_hip.h).
         d_input_ptrs: n_batches lists of `inputs` device pointers (or one flat list); d_cov_ptrs / d_spec_ptrs: lists of
         device pointers (0 = not wanted) or None."""
+        return self.prepare_batches(noutput_items, d_input_ptrs, d_cov_ptrs, d_spec_ptrs, d_max_ptrs, d_argmax_ptrs, stream)()
+
+    def prepare_batches(self, noutput_items, d_input_ptrs, d_cov_ptrs, d_spec_ptrs, d_max_ptrs, d_argmax_ptrs, stream=None):
+        """The argument marshalling of work_dev_batches done once: returns a callable that makes the C call (a C or C++
+        caller has its pointer arrays at hand; a Python caller that repeats a call should not rebuild them every time)."""
         nb = len(d_max_ptrs)
         flat = [p for b in d_input_ptrs for p in b] if nb and isinstance(d_input_ptrs[0], (list, tuple)) else list(d_input_ptrs)
         assert len(flat) == nb * self.inputs and len(d_argmax_ptrs) == nb
         opt = lambda ptrs: None if ptrs is None else ptr_array([int(p or 0) for p in ptrs])
-        return check(lib.doa_music_pipeline_work_dev_batches(
-            self._h, nb, int(noutput_items), ptr_array(flat), opt(d_cov_ptrs), opt(d_spec_ptrs), ptr_array(d_max_ptrs),
-            ptr_array(d_argmax_ptrs), _stream_ptr(stream)))
+        args = (self._h, nb, int(noutput_items), ptr_array(flat), opt(d_cov_ptrs), opt(d_spec_ptrs), ptr_array(d_max_ptrs),
+                ptr_array(d_argmax_ptrs), _stream_ptr(stream))
+        fn = lib.doa_music_pipeline_work_dev_batches
+        return lambda: check(fn(*args))
 
     def input_span(self, noutput_items) -> int:
         n = int(noutput_items)

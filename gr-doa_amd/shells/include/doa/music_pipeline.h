@@ -20,6 +20,17 @@ public:
     typedef DOA_SPTR<music_pipeline> sptr;
     static sptr make(int inputs, int snapshot_size, int overlap_size, int avg_method, float norm_spacing, int num_targets,
                      int pspectrum_len);
+
+    // For callers whose streams are ALREADY on the device (another accelerator block upstream, a capture ring in HBM): the
+    // same chain without the scheduler's host buffers -- n_batches batches of noutput_items (<= max_batch()) snapshots per
+    // call, overlapped by the library over the block's own lanes (doa_music_pipeline_work_dev_batches, include/doa_hip.h:
+    // pointer arrays as documented there; hip_stream a hipStream_t or DOA_STREAM_DETACHED, then synchronize_device()).
+    // Returns the snapshots produced or WORK_DONE after logging, like general_work.
+    virtual int work_device_batches(int n_batches, int noutput_items, const void *const *d_input_items,
+                                    void *const *d_spectrum_out, void *const *d_max_out, void *const *d_argmax_out,
+                                    void *hip_stream) = 0;
+    virtual int synchronize_device() = 0;
+    virtual int max_batch() const = 0;
 };
 
 }  // namespace doa

@@ -47,20 +47,30 @@ int work_failed(const char *what, int status)
 
 // Flowgraph-rate plumbing.  Under GNU Radio's default 64 KiB buffers these blocks see calls of a
 // handful of items, and a call costs 50-100 us of launches, copies and one stream synchronisation whatever its
-// size.  Two scheduler knobs change that, both set here from the environment so that a flowgraph needs no edit:
-//   DOA_GR_MIN_OUTPUT_BUFFER  items the block's output buffers must hold (default 2048; 0 = GNU Radio's default):
-//                             the scheduler then hands over up to half of that whenever upstream has it ready --
-//                             larger calls, no added latency, no change at end of stream;
-//   DOA_GR_OUTPUT_MULTIPLE    work() is only called with a multiple of this many items (default 1 = the reference's
-//                             scheduling).  For gr::block's with a decimation (autocorrelate, music_pipeline) GNU
-//                             Radio also sizes the INPUT buffers from it (2 x multiple x (snapshot - overlap) samples),
-//                             which is what lets a radio-rate flowgraph reach the PCIe-bound rate; the price is
-//                             GNU Radio's own: up to multiple - 1 trailing items are not processed when a finite
-//                             source ends.
-void apply_scheduling_hints(gr::block *b)
+// size.  Two scheduler knobs change that, both set here so that a flowgraph needs no edit:
+//   set_min_output_buffer    items the block's output buffers must hold: the scheduler then hands over up to half of that
+//                            whenever upstream has it ready -- larger calls, no added latency, no change at end of stream.
+//                            Default: a BYTE budget, not an item count -- GNU Radio allocates at least min_items x item size
+//                            per output ring (mapped twice by vmcircbuf), so a fixed 2048 items would be 8 MiB for a 1024-point
+//                            spectrum and 128 MiB for a 16384-point one.  min_items = clamp(2 MiB / largest output item, 1,
+//                            2048): 512 spectra of 1024 points, 2048 covariance matrices or angle pairs.
+//                            DOA_GR_MIN_OUTPUT_BUFFER=<items> overrides (0 = GNU Radio's default sizing).
+//   DOA_GR_OUTPUT_MULTIPLE   work() is only called with a multiple of this many items (default 1 = the reference's
+//                            scheduling).  For gr::block's with a decimation (autocorrelate, music_pipeline) GNU
+//                            Radio also sizes the INPUT buffers from it (2 x multiple x (snapshot - overlap) samples),
+//                            which is what lets a radio-rate flowgraph reach the PCIe-bound rate; the price is
+//                            GNU Radio's own: up to multiple - 1 trailing items are not processed when a finite
+//                            source ends.
+constexpr long kMinOutputBufferBytes = 2l << 20;
+void apply_scheduling_hints(gr::block *b, size_t largest_output_item_bytes)
 {
     const char *e = getenv("DOA_GR_MIN_OUTPUT_BUFFER");
-    const long min_buf = e ? atol(e) : 2048;
+    long min_buf;
+    if (e) min_buf = atol(e);
+    else {
+        min_buf = kMinOutputBufferBytes / (long)(largest_output_item_bytes ? largest_output_item_bytes : 1);
+        min_buf = min_buf < 1 ? 1 : (min_buf > 2048 ? 2048 : min_buf);
+    }
     if (min_buf > 0) b->set_min_output_buffer(min_buf);
     e = getenv("DOA_GR_OUTPUT_MULTIPLE");
     const int mult = e ? atoi(e) : 1;
@@ -82,7 +92,7 @@ public:
     {
         if (!d_h) throw_create("doa::autocorrelate");
         set_history(doa_autocorrelate_history(d_h));          // overlap_size + 1
-        apply_scheduling_hints(this);
+        apply_scheduling_hints(this, sizeof(gr_complex) * inputs * inputs);
     }
     ~autocorrelate_hip() override { doa_autocorrelate_destroy(d_h); }
 
@@ -114,7 +124,7 @@ public:
           d_h(doa_MUSIC_lin_array_create(norm_spacing, num_targets, num_ant_ele, pspectrum_len))
     {
         if (!d_h) throw_create("doa::MUSIC_lin_array");
-        apply_scheduling_hints(this);
+        apply_scheduling_hints(this, sizeof(float) * pspectrum_len);
     }
     ~MUSIC_lin_array_hip() override
     {
@@ -141,7 +151,7 @@ public:
           d_h(doa_find_local_max_create(num_max_vals, vector_len, x_min, x_max))
     {
         if (!d_h) throw_create("doa::find_local_max");
-        apply_scheduling_hints(this);
+        apply_scheduling_hints(this, num_max_vals * sizeof(float));
     }
     ~find_local_max_hip() override { doa_find_local_max_destroy(d_h); }
     int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) override
@@ -164,7 +174,7 @@ public:
           d_h(doa_rootMUSIC_linear_array_create(norm_spacing, num_targets, num_ant_ele))
     {
         if (!d_h) throw_create("doa::rootMUSIC_linear_array");
-        apply_scheduling_hints(this);
+        apply_scheduling_hints(this, num_targets * sizeof(float));
     }
     ~rootMUSIC_linear_array_hip() override { doa_rootMUSIC_linear_array_destroy(d_h); }
     int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) override
@@ -208,7 +218,7 @@ public:
           d_h(doa_calibrate_lin_array_create(norm_spacing, num_ant_ele, pilot_angle))
     {
         if (!d_h) throw_create("doa::calibrate_lin_array");
-        apply_scheduling_hints(this);
+        apply_scheduling_hints(this, num_ant_ele * sizeof(gr_complex));
     }
     ~calibrate_lin_array_hip() override { doa_calibrate_lin_array_destroy(d_h); }
     int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) override
@@ -241,7 +251,7 @@ public:
     {
         if (!d_h) throw_create("doa::music_pipeline");
         set_history(overlap_size + 1);                        // as doa::autocorrelate (autocorrelate_impl.cc:56-57)
-        apply_scheduling_hints(this);
+        apply_scheduling_hints(this, (size_t)pspectrum_len * sizeof(float));
     }
     ~music_pipeline_hip() override { doa_music_pipeline_destroy(d_h); }
 
@@ -249,6 +259,17 @@ public:
     {
         for (auto &n : ninput_items_required) n = d_nonoverlap * noutput_items;     // autocorrelate_impl.cc:75-80
     }
+
+    // device-resident callers (no scheduler buffers involved): several batches per call, overlapped over the handle's own lanes
+    int work_device_batches(int n_batches, int noutput_items, const void *const *d_input_items, void *const *d_spectrum_out,
+                            void *const *d_max_out, void *const *d_argmax_out, void *hip_stream) override
+    {
+        const int produced = doa_music_pipeline_work_dev_batches(d_h, n_batches, noutput_items, d_input_items, nullptr, d_spectrum_out,
+                                                                 d_max_out, d_argmax_out, hip_stream);
+        return produced < 0 ? work_failed("doa::music_pipeline", produced) : produced;
+    }
+    int synchronize_device() override { return doa_music_pipeline_synchronize(d_h) == 0 ? 0 : work_failed("doa::music_pipeline", -3); }
+    int max_batch() const override { return kMaxBatch; }
 
     int general_work(int noutput_items, gr_vector_int &, gr_vector_const_void_star &input_items,
                      gr_vector_void_star &output_items) override

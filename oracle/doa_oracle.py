@@ -195,6 +195,11 @@ def music_steering(norm_spacing: float, num_ant_ele: int, pspectrum_len: int,
     loc = music_array_loc(norm_spacing, num_ant_ele)
     theta = music_theta_grid(pspectrum_len)
     if precision == "f32":
+        # ASSUMPTION (parity unpinned): the reference writes an unqualified `cos(theta)` on a float (:103).  With <cmath>
+        # in scope and `using namespace std` that resolves to std::cos(float); through <math.h> alone to ::cos(double) on
+        # the promoted argument.  Which one its toolchain picked cannot be told from the source; the double form is taken
+        # here.  The two differ by at most one float ulp of the scalar (<= 4e-7 in the phase), far inside the reference's own
+        # fp32 error budget, and the f64 path below -- the one the device is held to -- does not depend on it.
         k = (-1.0 * 2 * np.pi * np.cos(theta.astype(np.float64))).astype(_F32)   # scalar -> float
         phase = (k[None, :] * loc[:, None]).astype(_F32)                          # float multiply
         return (np.cos(phase) + 1j * np.sin(phase)).astype(_C64)

@@ -19,7 +19,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -28,7 +28,7 @@ commands = {}
 cmd_file = os.path.join(src, "commands.txt")
 if os.path.exists(cmd_file):
     for line in open(cmd_file):
-        m = re.match(r"(\w+): (rocprofv3 .*)", line.strip())
+        m = re.match(r"(\w+): (.*rocprofv3 .*)", line.strip())
         if m:
             commands[m.group(1)] = m.group(2)
 
@@ -74,6 +74,7 @@ WORKLOADS = {
     "scan262144": {"batch": 262144, "alg": {"music_scan_peak1_kernel": 262144 * (2 * N * 8 + P * 4 + 8)}},
     "cfg4": {"batch": 4096, "alg": {"cov_mfma_kernel": 4096 * (16 * 1024 * 8 + 256 * 8),
                                       "music_evd_block16_kernel": 4096 * (256 * 8 + 32 * 8),
+                                      "music_evd_subspace_kernel": 4096 * (256 * 8 + 32 * 8),
                                       "music_scan_stream_kernel": 4096 * (32 * 8 + 4096 * 4),
                                       "music_scan_peak_long_kernel": 4096 * (32 * 8 + 4096 * 4 + 24),
                                       "find_local_max_stream_kernel": 4096 * (4096 * 4 + 24)}},
