@@ -335,7 +335,7 @@ __device__ __forceinline__ void lean_scan_item(const T (&c)[LeanRecord<N, T>::kL
         for (int j = 0; j < CH; j++)
             store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4((float)lane, (float)j, -1.f, -2.f));
         if (lane == 0) { pk_val_item[0] = 0.0f; pk_loc_item[0] = xs[lane]; }
-        return;                 // (nothing here depends on the item's record: the loop's scalar loads are never waited for)
+        return;                 // (nothing here depends on the item's record)
     }
     // pass 1: the null spectrum itself (no reciprocal), the minimum of each lane's 4-angle groups, the item minimum
     float qf[CH][4], cm[CH];
@@ -491,8 +491,10 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
     T zr[CH][4], zi[CH][4];
     lean_load_table<CH, T>(ztab, lane, zr, zi);
     // coefficient records arrive through scalar loads; the next item's record is requested before this item's
-    // arithmetic so that its latency hides behind it (two items ahead measured no better: 231 against 219-227 us per
-    // 262144 items; neither did sixteen consecutive items per wave and turn)
+    // arithmetic so that its latency hides behind it.  (Measured and not kept, all within +-2 % of this form per 262144 items:
+    // requests two items ahead; the request and its s_waitcnt placed by hand at the two ends of the item -- the compiler puts
+    // the wait behind pass 1 --; sixteen consecutive items per wave with the records staged through LDS; the last chunk of the
+    // table in LDS for five waves per SIMD.  DESIGN.md section 3.)
     T c[RL], c_next[RL];
     if (wave < n_items) {
 #pragma unroll

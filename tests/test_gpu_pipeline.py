@@ -378,3 +378,41 @@ def test_batches_entry_detached_and_adopted_streams():
         pipe.synchronize()
         for b in range(nb):
             assert torch.equal(am[b], ref_am[b]) and torch.equal(sp[b], ref_sp[b]), (adopt, b)
+
+
+def test_large_batch_scan_equals_small_batches():
+    """At large batches the lean scan kernel is launched with 16 instead of 12 waves per CU and every wave loops over ~34 items
+    (hand-placed record prefetch, music_scan_impl.hpp); one call over 140 000 snapshots must give the bits of the same
+    snapshots processed 4096 at a time, ragged tail and an irregular row included."""
+    N, K, P, M, d = 4, 16, 1024, 1, 0.5
+    n = 140000 + 777                                                  # > 32 runs of 16 per wave at 16 waves per CU, ragged
+    s, _ = doa.sim.make_batch_streams_torch(N, K, n, d, M, 15.0, seed=91, device="cuda")
+    s[1][K * 100017 + 3] = float("nan")                              # one irregular item inside a run
+    st = torch.cuda.current_stream()
+    big = doa.music_pipeline(N, K, 0, 0, d, M, P, n)
+    spec = torch.empty((n, P), dtype=torch.float32, device="cuda")
+    mx = torch.empty((n, M), dtype=torch.float32, device="cuda")
+    am = torch.empty((n, M), dtype=torch.float32, device="cuda")
+    big.work_dev(n, [t.data_ptr() for t in s], 0, spec.data_ptr(), mx.data_ptr(), am.data_ptr(), st)
+    small = doa.music_pipeline(N, K, 0, 0, d, M, P, 4096)
+    spec2 = torch.empty((4096, P), dtype=torch.float32, device="cuda")
+    mx2 = torch.empty((4096, M), dtype=torch.float32, device="cuda")
+    am2 = torch.empty((4096, M), dtype=torch.float32, device="cuda")
+    for i0 in list(range(0, n, 4096 * 7))[:5] + [96 * 1024, n - 4096 + 17 - 17]:     # a sample of chunks incl. the irregular item's and the tail
+        i0 = min(i0, n - 4096)
+        small.work_dev(4096, [t[i0 * K:].data_ptr() for t in s], 0, spec2.data_ptr(), mx2.data_ptr(), am2.data_ptr(), st)
+        torch.cuda.synchronize()
+        a, b = spec[i0:i0 + 4096], spec2
+        same = (a == b) | (torch.isnan(a) & torch.isnan(b))
+        assert bool(same.all()), i0
+        assert torch.equal(torch.nan_to_num(am[i0:i0 + 4096], nan=-1.0), torch.nan_to_num(am2, nan=-1.0)), i0
+        assert torch.equal(torch.nan_to_num(mx[i0:i0 + 4096], nan=-1.0), torch.nan_to_num(mx2, nan=-1.0)), i0
+    # and the stand-alone block (spectrum only) takes the same path at this size
+    blk = doa.MUSIC_lin_array(d, M, N, P)
+    cov = torch.empty((n, N * N), dtype=torch.complex64, device="cuda")
+    doa.autocorrelate(N, K, 0, 0).work_dev(n, [t.data_ptr() for t in s], cov.data_ptr(), st)
+    spec3 = torch.empty((n, P), dtype=torch.float32, device="cuda")
+    blk.work_dev(n, cov.data_ptr(), spec3.data_ptr(), st)
+    torch.cuda.synchronize()
+    same = (spec == spec3) | (torch.isnan(spec) & torch.isnan(spec3))
+    assert bool(same.all())
