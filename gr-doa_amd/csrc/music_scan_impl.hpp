@@ -30,6 +30,39 @@ template <int N, typename T> __device__ __forceinline__ T null_spectrum(const T 
     return fma((T)2, re, c[0]);
 }
 
+// The same arithmetic for U angles at once, the U Horner chains advanced step by step side by side (U independent
+// dependency chains in flight: what a kernel with few waves per SIMD needs to keep the FP64 pipe busy).
+template <int N, typename T, int U>
+__device__ __forceinline__ void null_spectrum_multi(const T (&c)[2 * N], const T (&zr)[U], const T (&zi)[U], float (&q)[U])
+{
+    if constexpr (N == 1) {
+#pragma unroll
+        for (int u = 0; u < U; u++) q[u] = (float)c[0];
+    } else {
+        T hr[U], hi[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { hr[u] = c[2 * (N - 1) - 1]; hi[u] = c[2 * (N - 1)]; }
+#pragma unroll
+        for (int l = N - 2; l >= 1; l--) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const T tr = fma(hr[u], zr[u], fma(-hi[u], zi[u], c[2 * l - 1]));
+                const T ti = fma(hr[u], zi[u], fma(hi[u], zr[u], c[2 * l]));
+                hr[u] = tr; hi[u] = ti;
+            }
+            // (left alone, instruction selection puts the chains back one after the other to save registers -- a scheduling
+            // barrier does not bind side-effect-free arithmetic; an empty asm that "modifies" all running values does)
+            static_assert(U == 4, "the ordering fence below names its operands");
+            asm volatile("" : "+v"(hr[0]), "+v"(hi[0]), "+v"(hr[1]), "+v"(hi[1]), "+v"(hr[2]), "+v"(hi[2]), "+v"(hr[3]), "+v"(hi[3]));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const T re = fma(hr[u], zr[u], -hi[u] * zi[u]);
+            q[u] = (float)fma((T)2, re, c[0]);
+        }
+    }
+}
+
 // ---- normalisation to the maximum: 10*log10(out/max(out)), out = 1/Q (reference :140-142) ------------------
 // The reference forms out = 1.0/Q (double division stored to float: correctly rounded) and divides by the
 // maximum in float; an angle is at exactly 0 dB iff its ROUNDED reciprocal equals the largest one (x/x == 1),
@@ -608,15 +641,16 @@ __global__ __launch_bounds__(256) void music_scan_stream_kernel(const T *__restr
 // SGPRs code as the stand-alone K5).  The two-launch form this replaces (music_scan_stream_kernel parks Q in the
 // output row, then find_local_max_stream_kernel reads the row back) moves the 4P-byte row through HBM four times:
 // write, read, write, read.  Rolled loops: ~100 VGPRs where a register-resident row plus peak_pick<16> needs 511.
-template <int N, typename T>
+template <int N, typename T, int ABL = 0>
 __global__ __launch_bounds__(256) void music_scan_peak_long_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                                    float *__restrict__ spec, int P, int n_items, int n_ant,
                                                                    const float *__restrict__ xaxis, float *__restrict__ pk_val,
                                                                    float *__restrict__ pk_loc, int M)
 {
     constexpr int PMAX = 4096;
-    __shared__ float rows[4][PMAX];               // 64 KiB per workgroup: two workgroups (8 waves) per CU; 10 waves per CU
-                                                  // as five 2-wave workgroups measured 12 % slower
+    // 65 KiB per workgroup: two workgroups (8 waves) per CU.  Position p lives at word p + (p >> 6): the passes below touch
+    // the row as 64 g + lane, the peak pick as 64 lane + i -- both conflict-free with one pad word per 64
+    __shared__ float rows[4][PMAX + PMAX / 64 + 4];      // (+4: the peak pick may read position P itself)
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = threadIdx.x / kWave;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + wib);
@@ -624,63 +658,90 @@ __global__ __launch_bounds__(256) void music_scan_peak_long_kernel(const T *__re
     const int rec = 2 * n_ant;
     const int G = P >> 6;
     float *lrow = rows[wib];
+    // The record is wave-uniform, but it must NOT travel through scalar registers: 2N - 1 doubles are 62 SGPRs at N = 16, the
+    // compiler spills them to lanes of a VGPR and reads every coefficient back with v_readlane inside the Horner steps (84 us
+    // per 4096 items of 4096 angles).  Lanes 0..rec-2 fetch the record with ONE coalesced load (zero beyond it: the
+    // polynomial is compiled for N >= n_ant), park it in LDS, and every lane reads all of it back into 2(2N - 1) VGPRs;
+    // two waves per SIMD (the LDS rows decide that) leave 256 VGPRs per wave.
+    __shared__ T recs[4][2 * N];
+    auto fetch_record = [&](int it) -> T { return (it < n_items && lane < rec - 1) ? coef[(size_t)it * rec + lane] : (T)0; };
+    T rec_next = fetch_record(wave);
     for (int item = wave; item < n_items; item += n_waves) {
         T c[2 * N];
+        if (lane < 2 * N) recs[wib][lane] = rec_next;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int k = 0; k < 2 * N; k++) c[k] = (k < rec - 1) ? coef[(size_t)item * rec + k] : (T)0;
-        // pass 1: Q (float) into the LDS row, and its minimum
+        for (int k = 0; k < 2 * N; k++) c[k] = recs[wib][k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        rec_next = fetch_record(item + n_waves);
+        // pass 1: Q (float) into the LDS row, and its minimum.  UZ angles per lane go through their Horner chains together
+        // (independent chains: the FP64 pipe is busy with two waves per SIMD), the table entries of the NEXT UZ steps are
+        // requested before the arithmetic of these starts.
         float mn = INFINITY;
-        // (table entries of UZ steps are requested before the first Horner starts: with two waves per SIMD the L2
-        // latency of a dependent load per step would otherwise be most of the pass)
-        constexpr int UZ = 8;
-        for (int g0 = 0; g0 < G; g0 += UZ) {
-            T zr[UZ], zi[UZ];
+        constexpr int UZ = 4;
+        T zr[UZ], zi[UZ], nr[UZ], ni[UZ];
+        auto fetch = [&](int g0, T (&a)[UZ], T (&b)[UZ]) {
 #pragma unroll
             for (int u = 0; u < UZ; u++) {
                 const int i = min(64 * (g0 + u) + lane, P - 1);
-                zr[u] = ztab[2 * (size_t)i]; zi[u] = ztab[2 * (size_t)i + 1];
+                a[u] = ztab[2 * (size_t)i]; b[u] = ztab[2 * (size_t)i + 1];
             }
+        };
+        fetch(0, nr, ni);
+        for (int g0 = 0; g0 < G; g0 += UZ) {
+#pragma unroll
+            for (int u = 0; u < UZ; u++) { zr[u] = nr[u]; zi[u] = ni[u]; }
+            if (g0 + UZ < G) fetch(g0 + UZ, nr, ni);
+            float q[UZ];
+            if constexpr (ABL & 1) {                      // lab: no Horner
+#pragma unroll
+                for (int u = 0; u < UZ; u++) q[u] = (float)(zr[u] + c[0]) + 2.0f;
+            } else null_spectrum_multi<N, T, UZ>(c, zr, zi, q);
 #pragma unroll
             for (int u = 0; u < UZ; u++) {
                 if (g0 + u < G) {
-                    const int i = 64 * (g0 + u) + lane;
-                    const float q = (float)null_spectrum<N, T>(c, zr[u], zi[u]);
-                    lrow[i] = q;
-                    mn = fminf(mn, q);
+                    lrow[65 * (g0 + u) + lane] = q[u];
+                    mn = fminf(mn, q[u]);
                 }
             }
         }
         mn = wave_allreduce_min(mn);
         float *grow = spec + (size_t)item * P;
         // pass 2: dB in place (each lane rewrites exactly the positions it wrote), one HBM write of the row
-        if (lean_norm_ok(mn)) {
+        if constexpr (ABL & 2) { if (mn == 12345.678f) grow[lane] = mn; }
+        else if (lean_norm_ok(mn)) {
             const LeanNorm nrm(mn);
 #pragma unroll 4
             for (int g = 0; g < G; g++) {
-                const int i = 64 * g + lane;
                 bool tie;
-                const float d = nrm.db(lrow[i], tie);
-                lrow[i] = d;
-                __builtin_nontemporal_store(d, grow + i);
+                const float d = nrm.db(lrow[65 * g + lane], tie);
+                lrow[65 * g + lane] = d;
+                __builtin_nontemporal_store(d, grow + 64 * g + lane);
             }
         } else {
             float mx = -INFINITY;
 #pragma unroll 4
-            for (int g = 0; g < G; g++) mx = fmaxf(mx, 1.0f / lrow[64 * g + lane]);
+            for (int g = 0; g < G; g++) mx = fmaxf(mx, 1.0f / lrow[65 * g + lane]);
             mx = wave_allreduce_max(mx);
             const float inv_mx = __builtin_amdgcn_rcpf(mx);
 #pragma unroll 4
             for (int g = 0; g < G; g++) {
-                const int i = 64 * g + lane;
-                const float d = db_from_ratio(1.0f / lrow[i], mx, inv_mx);
-                lrow[i] = d;
-                __builtin_nontemporal_store(d, grow + i);
+                const float d = db_from_ratio(1.0f / lrow[65 * g + lane], mx, inv_mx);
+                lrow[65 * g + lane] = d;
+                __builtin_nontemporal_store(d, grow + 64 * g + lane);
             }
         }
         // the row was written lane by lane; the peak pick reads it across lanes (same wave: LDS operations of one wave
         // complete in order, the fence only keeps the compiler from moving them)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        peak_pick_stream([&](int p) { return lrow[p]; }, P, M, xaxis, pk_val + (size_t)item * M, pk_loc + (size_t)item * M, lane);
+        if constexpr (!(ABL & 4)) {
+        struct PaddedRow {
+            const float *r, *mine;                         // mine = this lane's block
+            __device__ __forceinline__ float operator()(int p) const { return r[p + (p >> 6)]; }
+            __device__ __forceinline__ float blk(int i) const { return mine[i + (i >> 6)]; }
+        };
+        peak_pick_stream<true>(PaddedRow{lrow, lrow + 65 * lane}, P, M, xaxis, pk_val + (size_t)item * M, pk_loc + (size_t)item * M, lane);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
@@ -817,6 +878,14 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
         if (pk.val && pk.M >= 1 && P % 64 == 0 && P <= 4096) {
             int fb = (n_items + waves_per_block - 1) / waves_per_block;
             if (fb > cu_count() * 2) fb = cu_count() * 2;                 // 64 KiB of LDS per workgroup: two per CU
+#ifdef DOA_LAB
+            if constexpr (N == 16) {
+                const int abl = DOA_LAB_ENV_INT("DOA_SCAN_LONG_ABLATE", 0);
+#define DOA_LONG_ABL(A_) if (abl == A_) { hipLaunchKernelGGL((music_scan_peak_long_kernel<N, T, A_>), dim3(fb), block, 0, st, co, z, sp, P, n_items, n_ant, pk.xaxis, pk.val, pk.loc, pk.M); return true; }
+                DOA_LONG_ABL(1) DOA_LONG_ABL(2) DOA_LONG_ABL(4) DOA_LONG_ABL(6) DOA_LONG_ABL(7) DOA_LONG_ABL(3) DOA_LONG_ABL(5)
+#undef DOA_LONG_ABL
+            }
+#endif
             hipLaunchKernelGGL((music_scan_peak_long_kernel<N, T>), dim3(fb), block, 0, st, co, z, sp, P, n_items, n_ant,
                                pk.xaxis, pk.val, pk.loc, pk.M);
             return true;

@@ -231,7 +231,14 @@ __device__ __forceinline__ void peak_pick(const float (&v)[CH][4], int lane, int
 //     wave arg-max); the fill rule, index_max and the output ordering are those of peak_pick.
 // Any 1 <= L <= 4096.  ~1000 instructions and ~40 VGPRs per vector at L = 4096, where the register-resident CH = 16
 // kernel executes ~6500 with 230 VGPRs.
-template <class Fetch>
+// BLOCKED = true: the same masks built the other way round -- lane k walks ITS OWN 64 positions 64k .. 64k+63 serially (65
+// reads, a handful of vector instructions per position, no cross-lane traffic), flats inside the block are filled by the
+// same Kogge-Stone steps on the lane's own 64-bit masks, and the sign a block's trailing flats inherit -- that of the first
+// non-flat difference in any block to the right -- comes from two ballots (which blocks have a non-flat difference, and the
+// sign of their first one).  For callers whose v_at(64 k + i) is conflict-free across k (the long-spectrum scan kernel
+// pads its LDS row by one word per 64): 64 steps of a scalar dependency chain with a cross-lane shuffle, a readlane and
+// two ballots each become 64 independent lanes of straight-line code.
+template <bool BLOCKED = false, class Fetch>
 __device__ __forceinline__ void peak_pick_stream(Fetch v_at, int L, int M, const float *__restrict__ xaxis,
                                                  float *__restrict__ out_val_item, float *__restrict__ out_loc_item, int lane)
 {
@@ -241,7 +248,55 @@ __device__ __forceinline__ void peak_pick_stream(Fetch v_at, int L, int M, const
     float mv = 0.f;
     int mi = INT_MAX;
     unsigned long long neg_mine = 0ull;                  // lane k: resolved "sign == -1" mask of group k
-    {
+    if constexpr (BLOCKED) {
+        // contract of this form: L is a multiple of 64, v_at.blk(i) = the value at position 64 lane + i for 0 <= i <= 64
+        // (i = 64 of the last block is read, not used).  The maximum is not tracked here: it is looked for below only if the
+        // answer needs it.  Each compare lands in VCC and is shifted into the lane's mask word as the carry-in of
+        // w = w + w + carry (v_addc_co_u32): two vector instructions per position and mask.
+        const bool live = lane < G;
+        unsigned neg_w[2] = {0u, 0u}, pos_w[2] = {~0u, ~0u};
+        if (live) {
+            float cur = v_at.blk(64);
+            // descending walk, so that the first bit shifted in ends up as bit 31 of its word
+#pragma unroll
+            for (int h = 1; h >= 0; h--) {
+                unsigned nw = 0u, pw = 0u;
+#pragma unroll
+                for (int ii = 31; ii >= 0; ii--) {
+                    const float v = v_at.blk(32 * h + ii);              // cur = the value one position to the right
+                    asm("v_cmp_lt_f32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                        "v_cmp_gt_f32 vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+                        : "+v"(nw), "+v"(pw) : "v"(cur), "v"(v) : "vcc");
+                    cur = v;
+                }
+                neg_w[h] = nw; pos_w[h] = pw;
+            }
+            if (lane == G - 1) { neg_w[1] &= 0x7fffffffu; pos_w[1] |= 0x80000000u; }      // past the last difference: +1
+        }
+        const unsigned long long neg = ((unsigned long long)neg_w[1] << 32) | neg_w[0];
+        const unsigned long long pos = ((unsigned long long)pos_w[1] << 32) | pos_w[0];
+        const unsigned long long nonflat = neg | pos;
+        unsigned long long res = neg;
+        if (__builtin_amdgcn_ballot_w64(~nonflat != 0ull) != 0ull) {                   // some flat somewhere in the vector
+            // resolved sign at the first position of the block to the right = sign of the first non-flat difference at or
+            // beyond it (blocks past the end are all +1, so one always exists up to the last lane)
+            const bool any_nf = nonflat != 0ull;
+            const bool first_neg = any_nf && ((neg >> (any_nf ? __builtin_ctzll(nonflat) : 0)) & 1ull) != 0ull;
+            const unsigned long long has = __builtin_amdgcn_ballot_w64(any_nf);
+            const unsigned long long sgn = __builtin_amdgcn_ballot_w64(first_neg);
+            const unsigned long long right = (lane < 63) ? (has >> (lane + 1)) : 0ull;
+            unsigned long long carry_neg = 0ull;
+            if (right != 0ull) carry_neg = (sgn >> (lane + 1 + (int)__builtin_ctzll(right))) & 1ull;
+            unsigned long long prop = ~nonflat;
+            res |= prop & (carry_neg << 63);
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                res |= (res >> sh) & prop;
+                prop &= prop >> sh;
+            }
+        }
+        neg_mine = res;
+    } else {
         unsigned long long carry_neg = 0ull;             // resolved sign at the first position of the group to the right (0: +1)
         float above_first = 0.f;                         // value at the first position of the group to the right
         constexpr int U = 8;                             // groups per batch: U loads in flight per lane before any is consumed
@@ -283,8 +338,8 @@ __device__ __forceinline__ void peak_pick_stream(Fetch v_at, int L, int M, const
             }
         }
     }
-    wave_argbest(mv, mi);
-    const int idx_max = (mi == INT_MAX) ? 0 : mi;
+    if constexpr (!BLOCKED) wave_argbest(mv, mi);
+    int idx_max = (mi == INT_MAX) ? 0 : mi;
 
     int sel_idx = INT_MAX;
     float sel_val = 0.f;
@@ -314,6 +369,22 @@ __device__ __forceinline__ void peak_pick_stream(Fetch v_at, int L, int M, const
             }
             if (bi != INT_MAX && (bi >> 6) == lane) pk &= ~(1ull << (bi & 63));
             if (lane == r) { sel_idx = bi; sel_val = bv; }
+        }
+    }
+    if constexpr (BLOCKED) {
+        if (M == 1 || n_valid == 0) {                    // wave-uniform: only now is index_max part of the answer
+            if (lane < G) {
+                // ascending walk of the own block: ">" keeps the first occurrence, -inf and NaN never pass it
+                float best = -INFINITY;
+#pragma unroll 8
+                for (int i = 0; i < 64; i++) {
+                    const float v = v_at.blk(i);
+                    if (v > best) { best = v; mi = 64 * lane + i; }
+                }
+                mv = best;
+            }
+            wave_argbest(mv, mi);
+            idx_max = (mi == INT_MAX) ? 0 : mi;
         }
     }
     const int fill_idx = (M == 1 || n_valid == 0) ? idx_max : best_list_pos;   // reference quirk for 0 < n_valid < M (:153,160)
