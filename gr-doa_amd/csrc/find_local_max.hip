@@ -15,8 +15,10 @@
 // p = 256 j + 4 lane + e, i.e. 1 KiB contiguous per load instruction).  Neighbour signs cross
 // lanes by shuffles; flats (rare) are resolved by a ballot-based suffix scan in position order;
 // the top-M are M rounds of a wave arg-max.  Longer vectors (up to 4096), lengths that are not a multiple of
-// 4 and unaligned buffers take find_local_max_stream_kernel (sign masks in SGPRs, nothing of the vector
-// in registers); beyond 4096 elements a one-thread-per-vector fallback walks the reference's steps literally.
+// 4 and unaligned buffers take find_local_max_blocked_kernel (the vector staged once in a padded LDS row, lane k
+// walks positions 64k..64k+63; peak_device.hpp: peak_pick_stream<true>); at most 64 elements of such a vector:
+// find_local_max_stream_kernel (sign masks in SGPRs, nothing of the vector in registers); beyond 4096 elements a
+// one-thread-per-vector fallback walks the reference's steps literally.
 #include "kernels.hpp"
 #include "peak_device.hpp"
 
@@ -77,6 +79,68 @@ __global__ __launch_bounds__(256) void find_local_max_stream_kernel(const float 
     if (item >= n_items) return;
     const float *v_in = in + (size_t)item * L;
     peak_pick_stream([&](int p) { return v_in[p]; }, L, M, xaxis, out_val + (size_t)item * M, out_loc + (size_t)item * M, lane);
+}
+
+// The same through LDS (any 64 < L <= 4096, any alignment): the vector is fetched once with coalesced loads into a row
+// padded by one word per 64 (position p at word p + (p >> 6)), and the peak pick runs in its lane-blocked form: lane k walks
+// positions 64k .. 64k+63 of the row, conflict-free.  Per 4096 vectors of 4096 values: 16.8-17.7 us against the 23.0-24.3 of the
+// streaming mask kernel on MUSIC spectra, 29 against 125 on vectors with a peak every few positions.
+__global__ __launch_bounds__(256) void find_local_max_blocked_kernel(const float *__restrict__ in, const float *__restrict__ xaxis,
+                                                                     float *__restrict__ out_val, float *__restrict__ out_loc,
+                                                                     int L, int M, int n_items, int vec4)
+{
+    constexpr int LMAX = 4096;
+    __shared__ float rows[4][LMAX + LMAX / 64 + 4];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = threadIdx.x / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + wib);
+    const int n_waves = gridDim.x * (blockDim.x / kWave);
+    float *lrow = rows[wib];
+    struct PaddedRow {
+        const float *r, *mine;                             // mine = this lane's block
+        __device__ __forceinline__ float operator()(int p) const { return r[p + (p >> 6)]; }
+        __device__ __forceinline__ float blk(int i) const { return mine[i + (i >> 6)]; }
+    };
+    if (vec4) {
+        // L % 4 == 0 and 16-byte aligned rows: 1 KiB per load instruction, and the NEXT vector of this wave is fetched into
+        // registers while the peak pick of the current one runs (two LDS-limited waves per SIMD hide no HBM latency)
+        const int n4 = L >> 2;
+        float4 pre[LMAX / 256];
+        auto fetch = [&](int it) {
+            const float4 *src = reinterpret_cast<const float4 *>(in + (size_t)it * L);
+#pragma unroll
+            for (int j = 0; j < LMAX / 256; j++) {
+                const int q = lane + kWave * j;
+                if (q < n4) pre[j] = load_f4<true>(src + q);
+            }
+        };
+        if (wave < n_items) fetch(wave);
+        for (int item = wave; item < n_items; item += n_waves) {
+#pragma unroll
+            for (int j = 0; j < LMAX / 256; j++) {
+                const int q = lane + kWave * j;
+                if (q < n4) {
+                    float *d = lrow + 4 * q + (q >> 4);    // 4 consecutive positions never straddle a multiple of 64
+                    d[0] = pre[j].x; d[1] = pre[j].y; d[2] = pre[j].z; d[3] = pre[j].w;
+                }
+            }
+            // written position by position, read block by block (same wave: LDS operations of one wave complete in order,
+            // the fences only keep the compiler from moving them)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (item + n_waves < n_items) fetch(item + n_waves);
+            peak_pick_stream<true>(PaddedRow{lrow, lrow + 65 * lane}, L, M, xaxis, out_val + (size_t)item * M, out_loc + (size_t)item * M, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        return;
+    }
+    for (int item = wave; item < n_items; item += n_waves) {
+        const float *v_in = in + (size_t)item * L;
+#pragma unroll 4
+        for (int p = lane; p < L; p += kWave) lrow[p + (p >> 6)] = __builtin_nontemporal_load(v_in + p);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        peak_pick_stream<true>(PaddedRow{lrow, lrow + 65 * lane}, L, M, xaxis, out_val + (size_t)item * M, out_loc + (size_t)item * M, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
 }
 
 // Literal walk of the reference's steps, one thread per vector (any L >= 1).  `scratch` holds L
@@ -150,11 +214,17 @@ int launch_find_local_max(const PeakTables &t, int n_items, const void *d_in, vo
     }
     dim3 block(256), grid((n_items + 3) / 4);
     // short, 16-byte aligned vectors of a multiple-of-4 length: the vector lives in registers (CH float4 per
-    // lane); everything else up to 4096 elements: the streaming mask kernel (46.5 -> 23.7 us per 4096 vectors of 4096
-    // against the register-resident CH = 16 kernel it replaced)
+    // lane); everything else up to 4096 elements: the LDS-staged blocked kernel (46.5 -> 23.7 -> 17 us per 4096 vectors of
+    // 4096: register-resident CH = 16 kernel, streaming mask kernel, this one)
     const bool reg_ok = (L % 4 == 0) && L >= 4 && (reinterpret_cast<uintptr_t>(d_in) % 16 == 0);
     const bool use_reg = reg_ok && L <= 1024;
-    if (!use_reg)       hipLaunchKernelGGL(find_local_max_stream_kernel, grid, block, 0, st, in, x, ov, ol, L, M, n_items);
+    if (!use_reg && L > 64 && !DOA_LAB_ENV_INT("DOA_K5_STREAM", 0)) {
+        // 65 KiB of LDS per 4-wave workgroup: two per CU
+        int bb = (n_items + 3) / 4;
+        if (bb > cu_count() * 2) bb = cu_count() * 2;
+        hipLaunchKernelGGL(find_local_max_blocked_kernel, dim3(bb), block, 0, st, in, x, ov, ol, L, M, n_items, reg_ok ? 1 : 0);
+    }
+    else if (!use_reg)  hipLaunchKernelGGL(find_local_max_stream_kernel, grid, block, 0, st, in, x, ov, ol, L, M, n_items);
     else if (L <= 256)  hipLaunchKernelGGL(find_local_max_kernel<1>, grid, block, 0, st, in, x, ov, ol, L, M, n_items);
     else if (L <= 512)  hipLaunchKernelGGL(find_local_max_kernel<2>, grid, block, 0, st, in, x, ov, ol, L, M, n_items);
     else                hipLaunchKernelGGL(find_local_max_kernel<4>, grid, block, 0, st, in, x, ov, ol, L, M, n_items);

@@ -44,15 +44,24 @@ __device__ __forceinline__ void null_spectrum_multi(const T (&c)[2 * N], const T
         for (int u = 0; u < U; u++) { hr[u] = c[2 * (N - 1) - 1]; hi[u] = c[2 * (N - 1)]; }
 #pragma unroll
         for (int l = N - 2; l >= 1; l--) {
+            // one Horner step of all U chains: the 2U inner products first, then the 2U outer ones, so that no instruction
+            // depends on one of the 2U - 1 before it.  (Left alone, instruction selection puts the chains back one after the
+            // other to save registers -- a scheduling barrier does not bind side-effect-free arithmetic; an empty asm that
+            // "modifies" all running values does.)
+            static_assert(U == 4, "the ordering fences below name their operands");
+            T ir[U], ii[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const T tr = fma(hr[u], zr[u], fma(-hi[u], zi[u], c[2 * l - 1]));
-                const T ti = fma(hr[u], zi[u], fma(hi[u], zr[u], c[2 * l]));
+                ir[u] = fma(-hi[u], zi[u], c[2 * l - 1]);
+                ii[u] = fma(hi[u], zr[u], c[2 * l]);
+            }
+            asm volatile("" : "+v"(ir[0]), "+v"(ii[0]), "+v"(ir[1]), "+v"(ii[1]), "+v"(ir[2]), "+v"(ii[2]), "+v"(ir[3]), "+v"(ii[3]));
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const T tr = fma(hr[u], zr[u], ir[u]);
+                const T ti = fma(hr[u], zi[u], ii[u]);
                 hr[u] = tr; hi[u] = ti;
             }
-            // (left alone, instruction selection puts the chains back one after the other to save registers -- a scheduling
-            // barrier does not bind side-effect-free arithmetic; an empty asm that "modifies" all running values does)
-            static_assert(U == 4, "the ordering fence below names its operands");
             asm volatile("" : "+v"(hr[0]), "+v"(hi[0]), "+v"(hr[1]), "+v"(hi[1]), "+v"(hr[2]), "+v"(hi[2]), "+v"(hr[3]), "+v"(hi[3]));
         }
 #pragma unroll

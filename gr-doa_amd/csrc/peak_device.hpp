@@ -249,11 +249,11 @@ __device__ __forceinline__ void peak_pick_stream(Fetch v_at, int L, int M, const
     int mi = INT_MAX;
     unsigned long long neg_mine = 0ull;                  // lane k: resolved "sign == -1" mask of group k
     if constexpr (BLOCKED) {
-        // contract of this form: L is a multiple of 64, v_at.blk(i) = the value at position 64 lane + i for 0 <= i <= 64
-        // (i = 64 of the last block is read, not used).  The maximum is not tracked here: it is looked for below only if the
-        // answer needs it.  Each compare lands in VCC and is shifted into the lane's mask word as the carry-in of
-        // w = w + w + carry (v_addc_co_u32): two vector instructions per position and mask.
-        const bool live = lane < G;
+        // contract of this form: v_at.blk(i) = the value at position 64 lane + i, readable for 0 <= i <= 64 in every lane whose
+        // block starts inside the vector (what it returns at positions >= L is not used).  The maximum is not tracked here:
+        // it is looked for below only if the answer needs it.  Each compare lands in VCC and is shifted into the lane's
+        // mask word as the carry-in of w = w + w + carry (v_addc_co_u32): two vector instructions per position and mask.
+        const bool live = 64 * lane < L;
         unsigned neg_w[2] = {0u, 0u}, pos_w[2] = {~0u, ~0u};
         if (live) {
             float cur = v_at.blk(64);
@@ -271,7 +271,14 @@ __device__ __forceinline__ void peak_pick_stream(Fetch v_at, int L, int M, const
                 }
                 neg_w[h] = nw; pos_w[h] = pw;
             }
-            if (lane == G - 1) { neg_w[1] &= 0x7fffffffu; pos_w[1] |= 0x80000000u; }      // past the last difference: +1
+            // positions from the last one of the vector on have no difference: +1 (what the compares saw there is garbage)
+            const int t = L - 1 - 64 * lane;                            // >= 0 here
+            if (t < 64) {
+                const unsigned lo = (t < 32) ? (~0u << t) : 0u;
+                const unsigned hi = (t < 32) ? ~0u : (~0u << (t - 32));
+                neg_w[0] &= ~lo; neg_w[1] &= ~hi;
+                pos_w[0] |= lo; pos_w[1] |= hi;
+            }
         }
         const unsigned long long neg = ((unsigned long long)neg_w[1] << 32) | neg_w[0];
         const unsigned long long pos = ((unsigned long long)pos_w[1] << 32) | pos_w[0];
@@ -376,10 +383,11 @@ __device__ __forceinline__ void peak_pick_stream(Fetch v_at, int L, int M, const
             if (lane < G) {
                 // ascending walk of the own block: ">" keeps the first occurrence, -inf and NaN never pass it
                 float best = -INFINITY;
+                const int lim = L - 64 * lane;                          // positions of this block inside the vector
 #pragma unroll 8
                 for (int i = 0; i < 64; i++) {
                     const float v = v_at.blk(i);
-                    if (v > best) { best = v; mi = 64 * lane + i; }
+                    if (i < lim && v > best) { best = v; mi = 64 * lane + i; }
                 }
                 mv = best;
             }
