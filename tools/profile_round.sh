@@ -42,7 +42,10 @@ run trace_cfg3_root   $T -d $out/trace_cfg3_root   -- python3 tools/bench_kernel
 run trace_cfg4_n16    $T -d $out/trace_cfg4_n16    -- python3 tools/bench_kernels.py --N 16 --M 3 --P 4096 --stages pipe --reps 20
 run trace_flowgraph   $T -d $out/trace_flowgraph   -- python3 tools/bench_kernels.py --M 2 --K 2048 --ovl 512 --fb 1 --stages pipe --reps 40
 run trace_n8          $T -d $out/trace_n8          -- python3 tools/bench_kernels.py --N 8 --M 2 --stages pipe --reps 40
+# the stand-alone blocks on cfg4's spectra (MUSIC_lin_array: EVD + spectrum-only scan; find_local_max on 4096-element vectors)
+run trace_k5_long     $T -d $out/trace_k5_long     -- python3 tools/bench_kernels.py --N 16 --M 3 --P 4096 --stages music,peak --reps 40
 for ctr in FETCH_SIZE WRITE_SIZE; do
     run pmc_${ctr}_cfg4 --pmc $ctr --output-format csv -d $out/pmc_${ctr}_cfg4 -- python3 tools/bench_kernels.py --N 16 --M 3 --P 4096 --stages pipe --reps 6
+    run pmc_${ctr}_k5long --pmc $ctr --output-format csv -d $out/pmc_${ctr}_k5long -- python3 tools/bench_kernels.py --N 16 --M 3 --P 4096 --stages music,peak --reps 6
 done
 cat $out/commands.txt

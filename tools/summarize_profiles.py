@@ -78,6 +78,9 @@ WORKLOADS = {
                                       "music_scan_stream_kernel": 4096 * (32 * 8 + 4096 * 4),
                                       "music_scan_peak_long_kernel": 4096 * (32 * 8 + 4096 * 4 + 24),
                                       "find_local_max_stream_kernel": 4096 * (4096 * 4 + 24)}},
+    "k5long": {"batch": 4096, "alg": {"find_local_max_blocked_kernel": 4096 * (4096 * 4 + 24),
+                                        "music_scan_stream_kernel": 4096 * (32 * 8 + 4096 * 4),
+                                        "music_evd_subspace_kernel": 4096 * (256 * 8 + 32 * 8)}},
 }
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))       # (workload, kernel) -> counter -> values
 for run in sorted(commands):
