@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void music_scan_peak_long_kernel(const T *__re
         // the row was written lane by lane; the peak pick reads it across lanes (same wave: LDS operations of one wave
         // complete in order, the fence only keeps the compiler from moving them)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if constexpr (!(ABL & 4)) {
+        if (!(ABL & 4) && M > 0) {                   // M == 0: spectrum only (the stand-alone MUSIC_lin_array block)
         struct PaddedRow {
             const float *r, *mine;                         // mine = this lane's block
             __device__ __forceinline__ float operator()(int p) const { return r[p + (p >> 6)]; }
@@ -884,23 +884,26 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
     if (aligned && P > 2048 && sizeof(T) == 8 && !q) {
         // with the peak pick wanted (the pipeline) and P a multiple of 64 up to 4096: scan + K5 in one launch, the row staged in
         // LDS and written once (the two-launch form it replaced moved the row through HBM four times)
-        if (pk.val && pk.M >= 1 && P % 64 == 0 && P <= 4096) {
+        // (also without the peak pick -- the stand-alone MUSIC_lin_array block: same kernel, same bits, 56 against the 62 us
+        // per 4096 items of the two-pass kernel below that parks Q in the output row)
+        if ((!pk.val || pk.M >= 1) && P % 64 == 0 && P <= 4096) {
+            const int M_pick = pk.val ? pk.M : 0;
             int fb = (n_items + waves_per_block - 1) / waves_per_block;
             if (fb > cu_count() * 2) fb = cu_count() * 2;                 // 64 KiB of LDS per workgroup: two per CU
 #ifdef DOA_LAB
             if constexpr (N == 16) {
                 const int abl = DOA_LAB_ENV_INT("DOA_SCAN_LONG_ABLATE", 0);
-#define DOA_LONG_ABL(A_) if (abl == A_) { hipLaunchKernelGGL((music_scan_peak_long_kernel<N, T, A_>), dim3(fb), block, 0, st, co, z, sp, P, n_items, n_ant, pk.xaxis, pk.val, pk.loc, pk.M); return true; }
+#define DOA_LONG_ABL(A_) if (abl == A_) { hipLaunchKernelGGL((music_scan_peak_long_kernel<N, T, A_>), dim3(fb), block, 0, st, co, z, sp, P, n_items, n_ant, pk.xaxis, pk.val, pk.loc, M_pick); return pk.val != nullptr; }
                 DOA_LONG_ABL(1) DOA_LONG_ABL(2) DOA_LONG_ABL(4) DOA_LONG_ABL(6) DOA_LONG_ABL(7) DOA_LONG_ABL(3) DOA_LONG_ABL(5)
 #undef DOA_LONG_ABL
             }
 #endif
             hipLaunchKernelGGL((music_scan_peak_long_kernel<N, T>), dim3(fb), block, 0, st, co, z, sp, P, n_items, n_ant,
-                               pk.xaxis, pk.val, pk.loc, pk.M);
-            return true;
+                               pk.xaxis, pk.val, pk.loc, M_pick);
+            return pk.val != nullptr;
         }
-        // spectrum only (the stand-alone block), or lengths the fused kernel does not take: the rolled two-pass kernel; the
-        // peak pick, if any, is left to the caller (returns false)
+        // lengths the fused kernel does not take: the rolled two-pass kernel; the peak pick, if any, is left to the caller
+        // (returns false)
         int sb = (n_items + waves_per_block - 1) / waves_per_block;
         if (sb > cu_count() * 16 / waves_per_block) sb = cu_count() * 16 / waves_per_block;
         hipLaunchKernelGGL((music_scan_stream_kernel<N, T>), dim3(sb), block, 0, st, co, z, sp, P, n_items, n_ant);
