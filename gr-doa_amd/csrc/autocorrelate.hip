@@ -490,7 +490,8 @@ int launch_autocorrelate(int N, int K, int ovl, int avg, int n_out, const void *
     case 8: launch_wave<8>(g, vec2, st); break;
     default: {
         int blocks = (n_out + 3) / 4;
-        if (blocks > cu_count() * 4) blocks = cu_count() * 4;        // <= 16 waves per CU, grid-stride beyond
+        const int mfma_wpc = DOA_LAB_ENV_INT("DOA_COV_MFMA_WAVES_PER_CU", 16);
+        if (blocks > cu_count() * mfma_wpc / 4) blocks = cu_count() * mfma_wpc / 4;        // <= 16 waves per CU, grid-stride beyond
         if (vec2) hipLaunchKernelGGL(cov_mfma_kernel<true>, dim3(blocks), dim3(256), 0, st, g);
         else      hipLaunchKernelGGL(cov_mfma_kernel<false>, dim3(blocks), dim3(256), 0, st, g);
         if (avg == 1) {
