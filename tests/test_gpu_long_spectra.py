@@ -29,7 +29,7 @@ def _pipeline(x, N, K, d, M, P, n):
     return cov, spec, mx, am
 
 
-@pytest.mark.parametrize("N,M", [(16, 3), (16, 1), (4, 2), (8, 4), (12, 2)])
+@pytest.mark.parametrize("N,M", [(16, 3), (16, 1), (4, 2), (8, 4), (12, 2), (2, 1), (3, 1), (6, 2), (5, 2), (13, 3)])
 @pytest.mark.parametrize("P", [2112, 3008, 4096])
 def test_peaks_are_the_references_answer_on_the_kernels_own_spectrum(N, M, P):
     n, K, d = 96, 64, 0.5
