@@ -586,6 +586,16 @@ def main():
 
     prepared = {}
 
+    def prepare(first, count, with_spectrum=True):
+        """marshal the pointer arrays of one library call (a C caller has them at hand) -- host work, done for EVERY call of
+        this run before the first step is launched, so that nothing but the barrier sits between warm-up and timed region"""
+        key = (first, count, with_spectrum)
+        if batched and count > 0 and key not in prepared:
+            idx = [i % nbuf for i in range(first, first + count)]
+            prepared[key] = pipes[0].prepare_batches(BATCH, [in_ptrs[b] for b in idx], [cov[b].data_ptr() for b in idx],
+                                                     [spec[b].data_ptr() for b in idx] if with_spectrum else None,
+                                                     [mx[b].data_ptr() for b in idx], [am[b].data_ptr() for b in idx], doa.DETACHED)
+
     def run_steps(first, count, with_spectrum=True):
         """`count` steps starting at step index `first` (buffer set = step index mod nbuf)."""
         if not batched:
@@ -598,14 +608,9 @@ def main():
             return
         # detached: the inputs are resident and complete (synchronize before the region), the join is the contract's own
         # torch.cuda.synchronize() after the K steps -- no cross-stream event inside the timed region (they cost ~150 us per fork + join on
-        # this runtime).  The pointer arrays of a call are marshalled once (a C caller has them at hand).
-        key = (first, count, with_spectrum)
-        if key not in prepared:
-            idx = [i % nbuf for i in range(first, first + count)]
-            prepared[key] = pipes[0].prepare_batches(BATCH, [in_ptrs[b] for b in idx], [cov[b].data_ptr() for b in idx],
-                                                     [spec[b].data_ptr() for b in idx] if with_spectrum else None,
-                                                     [mx[b].data_ptr() for b in idx], [am[b].data_ptr() for b in idx], doa.DETACHED)
-        prepared[key]()                 # (every caller below follows with torch.cuda.synchronize(): the device-wide join)
+        # this runtime).
+        prepare(first, count, with_spectrum)
+        prepared[(first, count, with_spectrum)]()   # (every caller below follows with torch.cuda.synchronize(): the device-wide join)
 
     def barrier():
         torch.cuda.synchronize()
@@ -613,9 +618,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # host-side marshalling of every call below, before anything is launched
+    n_setup = max(n_streams, nbuf)
+    for call in ((0, n_setup, True), (0, args.warmup, True), (0, args.steps, True), (0, 8, False), (0, args.steps, False),
+                 (max(0, args.steps - n_streams), min(n_streams, args.steps), True)):
+        prepare(*call)
     # setup, not warm-up: touch every lane / stream / buffer set once, so that first-launch code loading and lazy
     # workspace allocation never fall into a short timed region whatever --warmup says
-    run_steps(0, max(n_streams, nbuf))
+    run_steps(0, n_setup)
     torch.cuda.synchronize()
     if args.warmup > 0:
         run_steps(0, args.warmup)
@@ -623,13 +633,6 @@ def main():
     # (synchronize), the closing barrier follows, and the job's time is the MAX over ranks -- the time from the common
     # start to the slowest rank's completion, without the closing collective's own latency (tens of microseconds of
     # RCCL launch + ring on 8 GPUs would otherwise be charged to a 20-step region of ~0.6 ms).
-    if batched:                                    # marshal the timed calls' pointer arrays before the clock starts
-        for ws_ in (True, False):
-            k_ = (0, args.steps, ws_)
-            idx_ = [i % nbuf for i in range(args.steps)]
-            prepared[k_] = pipes[0].prepare_batches(BATCH, [in_ptrs[b] for b in idx_], [cov[b].data_ptr() for b in idx_],
-                                                    [spec[b].data_ptr() for b in idx_] if ws_ else None,
-                                                    [mx[b].data_ptr() for b in idx_], [am[b].data_ptr() for b in idx_], doa.DETACHED)
     barrier()
     t0 = time.perf_counter()
     run_steps(0, args.steps)
