@@ -10,6 +10,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 namespace doa {
 bool find_local_max_fast_ok(int L, const void *d_in);
@@ -32,7 +33,7 @@ struct doa_music_pipeline {
     doa::DevBuf d_in[2], d_res;
     doa::DevBuf d_work[2];          // K1's piece sums (overlapping windows), one per copy/compute lane
     doa::PinnedBuf h_stage;         // scheduler-sized calls: one page-locked staging buffer, one copy each way
-    int fail_chunk = -1;            // doa_music_pipeline_inject_failure: one-shot, host-pointer entry only (tests)
+    int fail_chunk = -1;            // doa_music_pipeline_inject_failure: one-shot; host-pointer entry (chunk) or batches entry (batch) (tests)
     // doa_music_pipeline_work_dev_batches: the library's own overlap lanes (streams + one workspace each)
     struct Lane {
         hipStream_t st = nullptr;
@@ -304,6 +305,12 @@ int doa_music_pipeline_work_dev_batches(doa_music_pipeline_t *h, int n_batches, 
     }
     int rc = DOA_OK;
     for (int b = 0; b < n_batches && rc >= 0; b++) {
+        if (h->fail_chunk == b) {                          // doa_music_pipeline_inject_failure (tests), one-shot
+            h->fail_chunk = -1;
+            doa::set_error("music_pipeline_work_dev_batches: injected failure in batch %d", b);
+            rc = DOA_ERR_HIP;
+            break;
+        }
         auto &ln = h->lanes[(lane0 + b) % L];
         PipeWs ws;
         ws.coef = ln.coef.p; ws.cheb = ln.cheb.p; ws.spec_scratch = ln.spec.p; ws.work = ln.work.p; ws.scratch = &ln.scratch; ws.scratch_item_off = 0;
@@ -318,7 +325,16 @@ int doa_music_pipeline_work_dev_batches(doa_music_pipeline_t *h, int n_batches, 
         const hipError_t e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(caller, ln.done, 0) : e1;
         if (e2 != hipSuccess && rc >= 0) { doa::set_error("music_pipeline_work_dev_batches: join failed: %s", hipGetErrorString(e2)); rc = DOA_ERR_HIP; }
     }
-    return rc < 0 ? rc : n_batches * noutput_items;
+    if (rc < 0) {
+        // an error return means "nothing of this call is still running": what the lanes were handed before the failing
+        // launch is waited for here (detached callers included, who would otherwise have to know that they must still
+        // synchronise a call that failed)
+        const std::string msg = doa_last_error();
+        for (int u = 0; u < used; u++) (void)hipStreamSynchronize(h->lanes[(lane0 + u) % L].st);
+        doa::set_error("%s", msg.c_str());
+        return rc;
+    }
+    return n_batches * noutput_items;
 }
 
 int doa_music_pipeline_set_lane_streams(doa_music_pipeline_t *h, int n_lanes, void *const *hip_streams)
@@ -506,6 +522,8 @@ int doa_music_pipeline_lanes_idle(doa_music_pipeline_t *h)
     if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     for (auto st : h->hst)
         if (st && hipStreamQuery(st) != hipSuccess) return 0;
+    for (int l = 0; l < doa_music_pipeline::kMaxLanes; l++)
+        if (h->lanes[l].st && hipStreamQuery(h->lanes[l].st) != hipSuccess) return 0;
     return 1;
 }
 

@@ -339,12 +339,13 @@ DOA_HIP_API int doa_music_pipeline_set_stages(doa_music_pipeline_t *h, int stage
 DOA_HIP_API int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items,
                                         const void *const *input_items, void *cov_out,
                                         void *spectrum_out, void *max_out, void *argmax_out);
-/* Test aids for the error path of doa_music_pipeline_work (not for production use).  inject_failure: the NEXT
- * doa_music_pipeline_work call on this handle behaves as if a HIP call had failed in chunk `chunk_index` (0 = the first
- * ~32 MiB chunk, or the only one of a scheduler-sized call) after that chunk's uploads were enqueued; one-shot, -1
- * disarms.  Whatever fails inside the call, it returns only after BOTH of the handle's copy/compute lanes have been
- * synchronised, so no copy to or from the caller's host buffers is in flight afterwards; lanes_idle reports exactly that
- * (1 = both lanes idle, 0 = work pending, < 0 = error). */
+/* Test aids for the error paths of doa_music_pipeline_work and doa_music_pipeline_work_dev_batches (not for production
+ * use).  inject_failure: the NEXT such call on this handle behaves as if a HIP call had failed in chunk `chunk_index` (0 =
+ * the first ~32 MiB chunk, or the only one of a scheduler-sized call) after that chunk's uploads were enqueued -- for the
+ * batches entry: before batch `chunk_index` is launched, the earlier ones already running on their lanes; one-shot, -1
+ * disarms.  Whatever fails inside either call, it returns only after every lane it used has been synchronised (the
+ * detached form included), so nothing of a failed call is still running or copying afterwards; lanes_idle reports exactly
+ * that (1 = all lanes idle, 0 = work pending, < 0 = error). */
 DOA_HIP_API int doa_music_pipeline_inject_failure(doa_music_pipeline_t *h, int chunk_index);
 DOA_HIP_API int doa_music_pipeline_lanes_idle(doa_music_pipeline_t *h);
 

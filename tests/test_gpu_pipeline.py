@@ -416,3 +416,32 @@ def test_large_batch_scan_equals_small_batches():
     torch.cuda.synchronize()
     same = (spec == spec3) | (torch.isnan(spec) & torch.isnan(spec3))
     assert bool(same.all())
+
+
+@pytest.mark.parametrize("detached", [True, False])
+def test_batches_entry_failure_leaves_nothing_running(detached):
+    """An error return of doa_music_pipeline_work_dev_batches means nothing of the call is still running -- in the detached
+    form too, where the caller would otherwise have to know that a call that FAILED must still be synchronised.  The batches
+    launched before the failing one complete and are correct; the next call on the handle works."""
+    N, K, P, d, M, n, nb = 4, 1024, 1024, 0.5, 1, 2048, 6
+    s, th = doa.sim.make_batch_streams_torch(N, K, n * nb, d, M, 20.0, seed=21, device="cuda")
+    ins = [[t[b * n * K:].data_ptr() for t in s] for b in range(nb)]
+    mk = lambda shape: [torch.full(shape, -5.0, dtype=torch.float32, device="cuda") for _ in range(nb)]
+    spec, mx, am = mk((n, P)), mk((n, M)), mk((n, M))
+    pipe = doa.music_pipeline(N, K, 0, 0, d, M, P, max_batch=n)
+    st = doa.DETACHED if detached else torch.cuda.current_stream()
+    args = (n, ins, None, [t.data_ptr() for t in spec], [t.data_ptr() for t in mx], [t.data_ptr() for t in am], st)
+    pipe.inject_failure(4)
+    with pytest.raises(doa.DoaError) as ei:
+        pipe.work_dev_batches(*args)
+    assert ei.value.status == -3 and "injected failure in batch 4" in str(ei.value)
+    assert pipe.lanes_idle()                                           # no synchronize call needed after a failed call
+    torch.cuda.synchronize()
+    for b in range(4):                                                 # what was launched before the failure is complete
+        assert float(am[b].min()) > 0.0 and float((am[b][:, 0].cpu() - torch.from_numpy(th[b * n:(b + 1) * n, 0]).float()).abs().max()) <= 1.0
+    assert float(am[4].max()) == -5.0 and float(am[5].max()) == -5.0   # the failing batch and the one behind it never ran
+    assert pipe.work_dev_batches(*args) == n * nb                      # one-shot: disarmed
+    pipe.synchronize()
+    torch.cuda.synchronize()
+    for b in range(nb):
+        assert float((am[b][:, 0].cpu() - torch.from_numpy(th[b * n:(b + 1) * n, 0]).float()).abs().max()) <= 1.0
