@@ -85,12 +85,16 @@ __global__ __launch_bounds__(256) void find_local_max_stream_kernel(const float 
 // padded by one word per 64 (position p at word p + (p >> 6)), and the peak pick runs in its lane-blocked form: lane k walks
 // positions 64k .. 64k+63 of the row, conflict-free.  Per 4096 vectors of 4096 values: 16.8-17.7 us against the 23.0-24.3 of the
 // streaming mask kernel on MUSIC spectra, 29 against 125 on vectors with a peak every few positions.
+// BS = positions per lane: 64 for vectors of up to 4096 values, 16 up to 1024 (all lanes busy).
+template <int BS>
 __global__ __launch_bounds__(256) void find_local_max_blocked_kernel(const float *__restrict__ in, const float *__restrict__ xaxis,
                                                                      float *__restrict__ out_val, float *__restrict__ out_loc,
                                                                      int L, int M, int n_items, int vec4)
 {
-    constexpr int LMAX = 4096;
-    __shared__ float rows[4][LMAX + LMAX / 64 + 4];
+    constexpr int LMAX = 64 * BS;
+    constexpr int LOG_BS = (BS == 16) ? 4 : 6;
+    static_assert(BS == 16 || BS == 64, "block size");
+    __shared__ float rows[4][LMAX + 64 + 4];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = threadIdx.x / kWave;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + wib);
@@ -98,8 +102,8 @@ __global__ __launch_bounds__(256) void find_local_max_blocked_kernel(const float
     float *lrow = rows[wib];
     struct PaddedRow {
         const float *r, *mine;                             // mine = this lane's block
-        __device__ __forceinline__ float operator()(int p) const { return r[p + (p >> 6)]; }
-        __device__ __forceinline__ float blk(int i) const { return mine[i + (i >> 6)]; }
+        __device__ __forceinline__ float operator()(int p) const { return r[p + (p >> LOG_BS)]; }
+        __device__ __forceinline__ float blk(int i) const { return mine[i + (i >> LOG_BS)]; }
     };
     if (vec4) {
         // L % 4 == 0 and 16-byte aligned rows: 1 KiB per load instruction, and the NEXT vector of this wave is fetched into
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void find_local_max_blocked_kernel(const float
             for (int j = 0; j < LMAX / 256; j++) {
                 const int q = lane + kWave * j;
                 if (q < n4) {
-                    float *d = lrow + 4 * q + (q >> 4);    // 4 consecutive positions never straddle a multiple of 64
+                    float *d = lrow + 4 * q + (q >> (LOG_BS - 2));    // 4 consecutive positions never straddle a block
                     d[0] = pre[j].x; d[1] = pre[j].y; d[2] = pre[j].z; d[3] = pre[j].w;
                 }
             }
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void find_local_max_blocked_kernel(const float
             // the fences only keep the compiler from moving them)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (item + n_waves < n_items) fetch(item + n_waves);
-            peak_pick_stream<true>(PaddedRow{lrow, lrow + 65 * lane}, L, M, xaxis, out_val + (size_t)item * M, out_loc + (size_t)item * M, lane);
+            peak_pick_stream<true, BS>(PaddedRow{lrow, lrow + (BS + 1) * lane}, L, M, xaxis, out_val + (size_t)item * M, out_loc + (size_t)item * M, lane);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         return;
@@ -136,9 +140,9 @@ __global__ __launch_bounds__(256) void find_local_max_blocked_kernel(const float
     for (int item = wave; item < n_items; item += n_waves) {
         const float *v_in = in + (size_t)item * L;
 #pragma unroll 4
-        for (int p = lane; p < L; p += kWave) lrow[p + (p >> 6)] = __builtin_nontemporal_load(v_in + p);
+        for (int p = lane; p < L; p += kWave) lrow[p + (p >> LOG_BS)] = __builtin_nontemporal_load(v_in + p);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        peak_pick_stream<true>(PaddedRow{lrow, lrow + 65 * lane}, L, M, xaxis, out_val + (size_t)item * M, out_loc + (size_t)item * M, lane);
+        peak_pick_stream<true, BS>(PaddedRow{lrow, lrow + (BS + 1) * lane}, L, M, xaxis, out_val + (size_t)item * M, out_loc + (size_t)item * M, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
@@ -218,11 +222,19 @@ int launch_find_local_max(const PeakTables &t, int n_items, const void *d_in, vo
     // 4096: register-resident CH = 16 kernel, streaming mask kernel, this one)
     const bool reg_ok = (L % 4 == 0) && L >= 4 && (reinterpret_cast<uintptr_t>(d_in) % 16 == 0);
     const bool use_reg = reg_ok && L <= 1024;
-    if (!use_reg && L > 64 && !DOA_LAB_ENV_INT("DOA_K5_STREAM", 0)) {
+    const int k5_lab = DOA_LAB_ENV_INT("DOA_K5_STREAM", 0);      // lab: 1 = streaming mask kernel, 2 = register kernel for M > 1 too
+    if (L > 1024 && k5_lab != 1) {
         // 65 KiB of LDS per 4-wave workgroup: two per CU
         int bb = (n_items + 3) / 4;
         if (bb > cu_count() * 2) bb = cu_count() * 2;
-        hipLaunchKernelGGL(find_local_max_blocked_kernel, dim3(bb), block, 0, st, in, x, ov, ol, L, M, n_items, reg_ok ? 1 : 0);
+        hipLaunchKernelGGL(find_local_max_blocked_kernel<64>, dim3(bb), block, 0, st, in, x, ov, ol, L, M, n_items, reg_ok ? 1 : 0);
+    }
+    else if (L > 64 && (!use_reg || (M > 1 && k5_lab != 2)) && k5_lab != 1) {
+        // up to 1024 values: 16 positions per lane; also for aligned vectors when more than one peak is wanted (the
+        // register kernel's general peak pick costs more than the trip through LDS)
+        int bb = (n_items + 3) / 4;
+        if (bb > cu_count() * 4) bb = cu_count() * 4;
+        hipLaunchKernelGGL(find_local_max_blocked_kernel<16>, dim3(bb), block, 0, st, in, x, ov, ol, L, M, n_items, reg_ok ? 1 : 0);
     }
     else if (!use_reg)  hipLaunchKernelGGL(find_local_max_stream_kernel, grid, block, 0, st, in, x, ov, ol, L, M, n_items);
     else if (L <= 256)  hipLaunchKernelGGL(find_local_max_kernel<1>, grid, block, 0, st, in, x, ov, ol, L, M, n_items);

@@ -368,7 +368,7 @@ template <int N, int CH, typename T, bool MULTI, bool PEAKS = true, bool STORE =
 __device__ __forceinline__ void lean_scan_item(const T (&c)[LeanRecord<N, T>::kLen], const T (&zr)[CH][4], const T (&zi)[CH][4],
                                                const T *__restrict__ ztab, float *__restrict__ row,
                                                const float *__restrict__ xs, float *__restrict__ pk_val_item,
-                                               float *__restrict__ pk_loc_item, int M, int lane)
+                                               float *__restrict__ pk_loc_item, int M, int lane, float *lds_row = nullptr)
 {
     constexpr int P = 256 * CH;
     const LeanQ<N, T> Q(c);
@@ -394,6 +394,11 @@ __device__ __forceinline__ void lean_scan_item(const T (&c)[LeanRecord<N, T>::kL
     if (lean_norm_ok(mn)) {
         const LeanNorm nrm(mn);
         if constexpr (MULTI) {
+            // num_max_vals > 1: the dB row goes to HBM and, for the peak pick, into this wave's LDS row (position p at word
+            // p + p / BS, BS = P / 64 positions per lane), where find_local_max runs in its lane-blocked form
+            // (peak_device.hpp: every lane walks its own BS positions; 14.7 -> 10.6 us per 4096 items at P = 1024, M = 2 against
+            // the register-resident peak_pick<CH> this replaced)
+            constexpr int BS = P / 64, LOG_BS = (BS == 4) ? 2 : (BS == 8) ? 3 : 4;
 #pragma unroll
             for (int j = 0; j < CH; j++) {
 #pragma unroll
@@ -404,8 +409,24 @@ __device__ __forceinline__ void lean_scan_item(const T (&c)[LeanRecord<N, T>::kL
                 if constexpr (STORE)
                     store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
                                    make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
+                if constexpr (PEAKS) {
+                    const int p0 = 4 * lane + 256 * j;                 // 4 consecutive positions never straddle a block
+                    float *d = lds_row + p0 + (p0 >> LOG_BS);
+                    d[0] = qf[j][0]; d[1] = qf[j][1]; d[2] = qf[j][2]; d[3] = qf[j][3];
+                }
             }
-            if constexpr (PEAKS) peak_pick<CH>(qf, lane, P, M, xs, pk_val_item, pk_loc_item);
+            if constexpr (PEAKS) {
+                struct PaddedRow {
+                    const float *r, *mine;
+                    __device__ __forceinline__ float operator()(int p) const { return r[p + (p >> LOG_BS)]; }
+                    __device__ __forceinline__ float blk(int i) const { return mine[i + (i >> LOG_BS)]; }
+                };
+                // written position by position, read block by block (same wave: LDS operations of one wave complete in
+                // order, the fences only keep the compiler from moving them)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                peak_pick_stream<true, BS>(PaddedRow{lds_row, lds_row + (BS + 1) * lane}, P, M, xs, pk_val_item, pk_loc_item, lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
         } else {
             int pos = INT_MAX;
             float keep = 0.f;
@@ -523,6 +544,7 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
     constexpr int P = 256 * CH;
     constexpr int RL = LeanRecord<N, T>::kLen;
     __shared__ float xs[P];
+    __shared__ float prow[(MULTI && PEAKS) ? 4 : 1][(MULTI && PEAKS) ? P + 64 + 4 : 1];     // peak-pick rows, one per wave
     if constexpr (PEAKS) {
         for (int i = threadIdx.x; i < P; i += blockDim.x) xs[i] = xaxis[i];
         __syncthreads();
@@ -530,6 +552,7 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
     const int n_waves = gridDim.x * (blockDim.x / kWave);
+    float *lds_row = (MULTI && PEAKS) ? prow[threadIdx.x / kWave] : nullptr;
     T zr[CH][4], zi[CH][4];
     lean_load_table<CH, T>(ztab, lane, zr, zi);
     // coefficient records arrive through scalar loads; the next item's record is requested before this item's
@@ -551,7 +574,7 @@ __global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restri
             for (int i = 0; i < RL; i++) c_next[i] = coef[(size_t)nxt * RL + i];
         }
         lean_scan_item<N, CH, T, MULTI, PEAKS, STORE, ABL>(c, zr, zi, ztab, spec + (size_t)item * P, xs, pk_val + (size_t)item * M,
-                                                          pk_loc + (size_t)item * M, M, lane);
+                                                          pk_loc + (size_t)item * M, M, lane, lds_row);
     }
 }
 

@@ -238,31 +238,38 @@ __device__ __forceinline__ void peak_pick(const float (&v)[CH][4], int lane, int
 // sign of their first one).  For callers whose v_at(64 k + i) is conflict-free across k (the long-spectrum scan kernel
 // pads its LDS row by one word per 64): 64 steps of a scalar dependency chain with a cross-lane shuffle, a readlane and
 // two ballots each become 64 independent lanes of straight-line code.
-template <bool BLOCKED = false, class Fetch>
+// BS (blocked form only): positions per lane, a power of two from 4 to 64 with L <= 64 BS -- 64 for vectors of up to 4096
+// values, L / 64 for the short spectra of the lean scan kernels (all 64 lanes busy, BS steps each).
+template <bool BLOCKED = false, int BS = 64, class Fetch>
 __device__ __forceinline__ void peak_pick_stream(Fetch v_at, int L, int M, const float *__restrict__ xaxis,
                                                  float *__restrict__ out_val_item, float *__restrict__ out_loc_item, int lane)
 {
-    const int G = (L + 63) >> 6;                         // groups of 64 positions (<= 64)
+    static_assert(BLOCKED || BS == 64, "the mask form works in groups of 64");
+    static_assert(BS == 4 || BS == 8 || BS == 16 || BS == 32 || BS == 64, "block size");
+    constexpr int LOG_BS = (BS == 4) ? 2 : (BS == 8) ? 3 : (BS == 16) ? 4 : (BS == 32) ? 5 : 6;
+    constexpr unsigned long long kBlockMask = (BS == 64) ? ~0ull : ((1ull << (BS & 63)) - 1ull);
+    const int G = (L + BS - 1) >> LOG_BS;                // blocks of BS positions (<= 64)
 
     // arma index_max (op_max::direct_max): first occurrence of the maximum; NaN and -inf never win; none -> 0
     float mv = 0.f;
     int mi = INT_MAX;
-    unsigned long long neg_mine = 0ull;                  // lane k: resolved "sign == -1" mask of group k
+    unsigned long long neg_mine = 0ull;                  // lane k: resolved "sign == -1" mask of block k
     if constexpr (BLOCKED) {
-        // contract of this form: v_at.blk(i) = the value at position 64 lane + i, readable for 0 <= i <= 64 in every lane whose
+        // contract of this form: v_at.blk(i) = the value at position BS lane + i, readable for 0 <= i <= BS in every lane whose
         // block starts inside the vector (what it returns at positions >= L is not used).  The maximum is not tracked here:
         // it is looked for below only if the answer needs it.  Each compare lands in VCC and is shifted into the lane's
         // mask word as the carry-in of w = w + w + carry (v_addc_co_u32): two vector instructions per position and mask.
-        const bool live = 64 * lane < L;
-        unsigned neg_w[2] = {0u, 0u}, pos_w[2] = {~0u, ~0u};
+        const bool live = BS * lane < L;
+        constexpr int W = (BS + 31) / 32, WB = (BS < 32) ? BS : 32;          // mask words per lane, bits per word
+        unsigned neg_w[2] = {0u, 0u}, pos_w[2] = {(unsigned)kBlockMask, (unsigned)(kBlockMask >> 32)};
         if (live) {
-            float cur = v_at.blk(64);
-            // descending walk, so that the first bit shifted in ends up as bit 31 of its word
+            float cur = v_at.blk(BS);
+            // descending walk, so that the first bit shifted in ends up as the top bit of its word
 #pragma unroll
-            for (int h = 1; h >= 0; h--) {
+            for (int h = W - 1; h >= 0; h--) {
                 unsigned nw = 0u, pw = 0u;
 #pragma unroll
-                for (int ii = 31; ii >= 0; ii--) {
+                for (int ii = WB - 1; ii >= 0; ii--) {
                     const float v = v_at.blk(32 * h + ii);              // cur = the value one position to the right
                     asm("v_cmp_lt_f32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
                         "v_cmp_gt_f32 vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
@@ -271,20 +278,18 @@ __device__ __forceinline__ void peak_pick_stream(Fetch v_at, int L, int M, const
                 }
                 neg_w[h] = nw; pos_w[h] = pw;
             }
-            // positions from the last one of the vector on have no difference: +1 (what the compares saw there is garbage)
-            const int t = L - 1 - 64 * lane;                            // >= 0 here
-            if (t < 64) {
-                const unsigned lo = (t < 32) ? (~0u << t) : 0u;
-                const unsigned hi = (t < 32) ? ~0u : (~0u << (t - 32));
-                neg_w[0] &= ~lo; neg_w[1] &= ~hi;
-                pos_w[0] |= lo; pos_w[1] |= hi;
-            }
         }
-        const unsigned long long neg = ((unsigned long long)neg_w[1] << 32) | neg_w[0];
-        const unsigned long long pos = ((unsigned long long)pos_w[1] << 32) | pos_w[0];
+        unsigned long long neg = ((unsigned long long)neg_w[1] << 32) | neg_w[0];
+        unsigned long long pos = ((unsigned long long)pos_w[1] << 32) | pos_w[0];
+        // positions from the last one of the vector on have no difference: +1 (what the compares saw there is garbage)
+        const int t = L - 1 - BS * lane;
+        if (live && t < BS) {
+            const unsigned long long beyond = (~0ull << t) & kBlockMask;
+            neg &= ~beyond; pos |= beyond;
+        }
         const unsigned long long nonflat = neg | pos;
         unsigned long long res = neg;
-        if (__builtin_amdgcn_ballot_w64(~nonflat != 0ull) != 0ull) {                   // some flat somewhere in the vector
+        if (__builtin_amdgcn_ballot_w64((~nonflat & kBlockMask) != 0ull) != 0ull) {    // some flat somewhere in the vector
             // resolved sign at the first position of the block to the right = sign of the first non-flat difference at or
             // beyond it (blocks past the end are all +1, so one always exists up to the last lane)
             const bool any_nf = nonflat != 0ull;
@@ -294,10 +299,10 @@ __device__ __forceinline__ void peak_pick_stream(Fetch v_at, int L, int M, const
             const unsigned long long right = (lane < 63) ? (has >> (lane + 1)) : 0ull;
             unsigned long long carry_neg = 0ull;
             if (right != 0ull) carry_neg = (sgn >> (lane + 1 + (int)__builtin_ctzll(right))) & 1ull;
-            unsigned long long prop = ~nonflat;
-            res |= prop & (carry_neg << 63);
+            unsigned long long prop = ~nonflat & kBlockMask;
+            res |= prop & (carry_neg << (BS - 1));
 #pragma unroll
-            for (int sh = 1; sh < 64; sh <<= 1) {
+            for (int sh = 1; sh < BS; sh <<= 1) {
                 res |= (res >> sh) & prop;
                 prop &= prop >> sh;
             }
@@ -354,7 +359,7 @@ __device__ __forceinline__ void peak_pick_stream(Fetch v_at, int L, int M, const
     if (M > 1) {
         // peaks: s[p-1] == +1 and s[p] == -1, 1 <= p <= L-2 (positions >= L-1 carry +1, so they never qualify)
         const unsigned long long below = __shfl_up(neg_mine, 1, kWave);
-        unsigned long long pk = neg_mine & ~((neg_mine << 1) | ((lane > 0) ? (below >> 63) : 0ull));
+        unsigned long long pk = neg_mine & ~((neg_mine << 1) | ((lane > 0) ? (below >> (BS - 1)) : 0ull)) & kBlockMask;
         if (lane == 0) pk &= ~1ull;
         const unsigned long long pk_all = pk;
         n_valid = wave_sum_int(__builtin_popcountll(pk));
@@ -363,18 +368,18 @@ __device__ __forceinline__ void peak_pick_stream(Fetch v_at, int L, int M, const
             float bv = 0.f;
             int bi = INT_MAX;
             for (unsigned long long m = pk; m != 0ull; m &= m - 1ull) {
-                const int pp = 64 * lane + (int)__builtin_ctzll(m);
+                const int pp = BS * lane + (int)__builtin_ctzll(m);
                 const float val = v_at(pp);
                 if (cand_better(val, pp, bv, bi)) { bv = val; bi = pp; }
             }
             wave_argbest(bv, bi);
             if (r == 0) {
                 // position of the best peak inside the ascending peak list (= #peaks before it)
-                const int rel = bi - 64 * lane;
-                const unsigned long long lower = (rel >= 64) ? ~0ull : ((rel <= 0) ? 0ull : ((1ull << rel) - 1ull));
+                const int rel = bi - BS * lane;
+                const unsigned long long lower = (rel >= BS) ? ~0ull : ((rel <= 0) ? 0ull : ((1ull << rel) - 1ull));
                 best_list_pos = wave_sum_int(__builtin_popcountll(pk_all & lower));
             }
-            if (bi != INT_MAX && (bi >> 6) == lane) pk &= ~(1ull << (bi & 63));
+            if (bi != INT_MAX && (bi >> LOG_BS) == lane) pk &= ~(1ull << (bi & (BS - 1)));
             if (lane == r) { sel_idx = bi; sel_val = bv; }
         }
     }
@@ -383,11 +388,11 @@ __device__ __forceinline__ void peak_pick_stream(Fetch v_at, int L, int M, const
             if (lane < G) {
                 // ascending walk of the own block: ">" keeps the first occurrence, -inf and NaN never pass it
                 float best = -INFINITY;
-                const int lim = L - 64 * lane;                          // positions of this block inside the vector
+                const int lim = L - BS * lane;                          // positions of this block inside the vector
 #pragma unroll 8
-                for (int i = 0; i < 64; i++) {
+                for (int i = 0; i < BS; i++) {
                     const float v = v_at.blk(i);
-                    if (i < lim && v > best) { best = v; mi = 64 * lane + i; }
+                    if (i < lim && v > best) { best = v; mi = BS * lane + i; }
                 }
                 mv = best;
             }
