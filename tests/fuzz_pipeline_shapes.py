@@ -1,0 +1,57 @@
+"""One-off fuzz of the fused pipeline over array sizes, source counts and spectrum lengths (every scan kernel family: lean,
+lean multi-peak, general, long-spectrum LDS-row, two-pass): the peak ports must be the reference's find_local_max on the
+pipeline's OWN spectrum bit for bit, the spectrum must sit on the fp64 evaluation of the reference's formulas, and the
+stand-alone blocks chained by hand must give the pipeline's bits.
+usage: python tests/fuzz_pipeline_shapes.py [n_cases] [seed]
+(lives under tests/ because it checks against the oracle, which only test code may import)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "gr-doa_amd", "python"), os.path.join(ROOT, "oracle")]
+import numpy as np
+import doa
+import doa_oracle as oracle
+
+
+def run(n_cases=60, seed=0, verbose=True):
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for case in range(n_cases):
+        N = int(rng.integers(2, 17))
+        M = int(rng.integers(1, min(N, 5)))
+        P = int(rng.choice([256, 512, 1024, 1000, 768, 2048, 1536, 2112, 3008, 4096, 2500, 4000, 64 * int(rng.integers(33, 65))]))
+        K = int(rng.choice([16, 64, 256]))
+        ovl = int(rng.choice([0, 0, K // 4]))
+        fb = int(rng.integers(0, 2))
+        n = int(rng.integers(1, 40))
+        d = float(rng.choice([0.5, 0.4, 0.44]))
+        th = np.sort(rng.uniform(25.0, 155.0, M)) + 4.0 * np.arange(M)
+        span = (n - 1) * (K - ovl) + K
+        x = doa.sim.make_streams(N, span, list(th), d, snr_db=float(rng.choice([5.0, 20.0])), seed=int(rng.integers(1 << 30)))
+        pipe = doa.music_pipeline(N, K, ovl, fb, d, M, P, max_batch=n)
+        mx, am = np.empty((n, M), np.float32), np.empty((n, M), np.float32)
+        cov, spec = np.empty((n, N * N), np.complex64), np.empty((n, P), np.float32)
+        pipe.work(n, [x[k] for k in range(N)], mx, am, cov_out=cov, spectrum_out=spec)
+        o0, o1 = oracle.find_local_max(spec, M, P, 0.0, 180.0)
+        s64 = oracle.music_lin_array(cov, d, M, N, P, "f64")
+        # the separate blocks on the same covariance items
+        blk, pk = doa.MUSIC_lin_array(d, M, N, P), doa.find_local_max(M, P, 0.0, 180.0)
+        spec2 = np.empty((n, P), np.float32)
+        blk.work(n, [cov], [spec2])
+        v0, v1 = np.empty((n, M), np.float32), np.empty((n, M), np.float32)
+        pk.work(n, [spec2], [v0, v1])
+        q0, q1 = oracle.find_local_max(spec2, M, P, 0.0, 180.0)
+        ok = (np.array_equal(mx, o0) and np.array_equal(am, o1) and np.array_equal(v0, q0) and np.array_equal(v1, q1)
+              and np.abs(spec - s64).max() <= 2e-4 and np.abs(spec2 - s64).max() <= 2e-4
+              and np.all(spec.max(axis=1) == 0.0) and np.all(spec2.max(axis=1) == 0.0))
+        if not ok:
+            bad += 1
+            if verbose:
+                print(f"case {case}: MISMATCH N={N} M={M} P={P} K={K} ovl={ovl} fb={fb} n={n}: peaks {np.array_equal(mx, o0)}/{np.array_equal(am, o1)} "
+                      f"blocks {np.array_equal(v0, q0)}/{np.array_equal(v1, q1)} spec err {np.abs(spec - s64).max():.2e} / {np.abs(spec2 - s64).max():.2e}")
+    if verbose:
+        print(f"{n_cases} cases, {bad} mismatches")
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 0)
