@@ -40,14 +40,25 @@ def run(n_cases=60, seed=0, verbose=True):
         v0, v1 = np.empty((n, M), np.float32), np.empty((n, M), np.float32)
         pk.work(n, [spec2], [v0, v1])
         q0, q1 = oracle.find_local_max(spec2, M, P, 0.0, 180.0)
-        ok = (np.array_equal(mx, o0) and np.array_equal(am, o1) and np.array_equal(v0, q0) and np.array_equal(v1, q1)
+        # Root-MUSIC on the same covariance items against the fp64 oracle (angles to 1e-3 degrees; rows where the oracle itself
+        # reports no angle -- NaN -- must be NaN here too)
+        root = doa.rootMUSIC_linear_array(d, M, N)
+        ang = np.empty((n, M), np.float32)
+        try:
+            root.work(n, [cov], [ang])
+        except doa.DoaError:
+            pass                                                        # DOA_ERR_NUMERIC rows: the others are still written
+        a64 = oracle.root_music(cov, d, M, N, "f64")
+        both = np.isfinite(a64) & np.isfinite(ang)
+        root_ok = np.array_equal(np.isfinite(a64), np.isfinite(ang)) and (not both.any() or np.abs(ang[both] - a64[both]).max() <= 1e-3)
+        ok = (root_ok and np.array_equal(mx, o0) and np.array_equal(am, o1) and np.array_equal(v0, q0) and np.array_equal(v1, q1)
               and np.abs(spec - s64).max() <= 2e-4 and np.abs(spec2 - s64).max() <= 2e-4
               and np.all(spec.max(axis=1) == 0.0) and np.all(spec2.max(axis=1) == 0.0))
         if not ok:
             bad += 1
             if verbose:
                 print(f"case {case}: MISMATCH N={N} M={M} P={P} K={K} ovl={ovl} fb={fb} n={n}: peaks {np.array_equal(mx, o0)}/{np.array_equal(am, o1)} "
-                      f"blocks {np.array_equal(v0, q0)}/{np.array_equal(v1, q1)} spec err {np.abs(spec - s64).max():.2e} / {np.abs(spec2 - s64).max():.2e}")
+                      f"root {root_ok} blocks {np.array_equal(v0, q0)}/{np.array_equal(v1, q1)} spec err {np.abs(spec - s64).max():.2e} / {np.abs(spec2 - s64).max():.2e}")
     if verbose:
         print(f"{n_cases} cases, {bad} mismatches")
     return bad
