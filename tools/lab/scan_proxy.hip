@@ -26,6 +26,14 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+#ifdef FP32
+typedef float real_t;      // the same instruction stream in float: separates issue time from what FP64 costs otherwise (power, clocks)
+#else
+typedef double real_t;
+#endif
+#ifndef XTRA
+#define XTRA 0          // extra FMA64 per angle: the shipped kernel's arithmetic alone takes 143 us per 262144 rows, this proxy's 106 at XTRA = 0
+#endif
 
 __device__ __forceinline__ float wave_min(float v)
 {
@@ -53,19 +61,20 @@ struct Params {
 
 // one item for a wave whose first chunk is R (compile time, so that register arrays keep static indices)
 template <int ARITH, int STORE, int PIPE, int R, int PK = 1, int COOP = 0>
-__device__ __forceinline__ void item_body(const Params &p, int item, int lane, const double (&zr)[4][4], const double (&zi)[4][4],
+__device__ __forceinline__ void item_body(const Params &p, int item, int lane, const real_t (&zr)[4][4], const real_t (&zi)[4][4],
                                           float (&held)[4][4], float *&held_row)
 {
-    double c[8];
+    real_t c[8];
     if constexpr (ARITH == 3 || ARITH == 4) {           // 3: no record loads at all (stores only); 4: arithmetic on a constant record
 #pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = 1.0 + 0.125 * k + 1e-9 * item;
+        for (int k = 0; k < 8; k++) c[k] = (real_t)(1.0 + 0.125 * k + 1e-9 * item);
     } else {
 #pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = p.coef[(size_t)item * 8 + k];
+        for (int k = 0; k < 8; k++) c[k] = (real_t)p.coef[(size_t)item * 8 + k];
     }
     float *row = p.spec + (size_t)item * 1024;
     float qf[4][4], cm[4];
+    if constexpr (COOP == 3) __builtin_amdgcn_s_barrier();
     // pass 1
 #pragma unroll
     for (int jj = 0; jj < 4; jj++) {
@@ -73,9 +82,11 @@ __device__ __forceinline__ void item_body(const Params &p, int item, int lane, c
         if constexpr (ARITH == 1 || ARITH == 4) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const double cs = zr[j][e], sn = zi[j][e];
-                const double A = fma(fma(fma(c[3], cs, c[2]), cs, c[1]), cs, c[0]);
-                const double B = fma(fma(c[6], cs, c[5]), cs, c[4]);
+                const real_t cs = zr[j][e], sn = zi[j][e];
+                const real_t A = fma(fma(fma(c[3], cs, c[2]), cs, c[1]), cs, c[0]);
+                real_t B = fma(fma(c[6], cs, c[5]), cs, c[4]);
+#pragma unroll
+                for (int x = 0; x < XTRA; x++) B = fma(B, sn, c[7]);
                 qf[j][e] = (float)fma(sn, B, A);
             }
         } else {
@@ -83,6 +94,7 @@ __device__ __forceinline__ void item_body(const Params &p, int item, int lane, c
             for (int e = 0; e < 4; e++) qf[j][e] = (float)c[e] + lane;
         }
         cm[j] = fminf(fminf(qf[j][0], qf[j][1]), fminf(qf[j][2], qf[j][3]));
+        if constexpr (COOP == 4) { if (jj == 0) __builtin_amdgcn_s_barrier(); }
         if constexpr (PIPE == 1 && STORE) { if (held_row) st4<STORE>(held_row + 4 * lane + 256 * j, held[j]); }
         if constexpr (PIPE == 2 && STORE) { if ((jj & 1) && held_row) { const int h = (((jj >> 1)) + R) & 3; st4<STORE>(held_row + 4 * lane + 256 * h, held[h]); } }
     }
@@ -95,7 +107,7 @@ __device__ __forceinline__ void item_body(const Params &p, int item, int lane, c
         for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(7);
     }
     const float inv = (ARITH == 1 || ARITH == 4) ? __builtin_amdgcn_rcpf(mn) * 1.0000002f : 1.0f;
-    if constexpr (COOP == 1) __syncthreads();            // the workgroup's waves enter pass 2 (and its stores) together
+    if constexpr (COOP == 1 || COOP == 4) __builtin_amdgcn_s_barrier();            // the workgroup's waves enter pass 2 (and its stores) together
     // pass 2
 #pragma unroll
     for (int jj = 0; jj < 4; jj++) {
@@ -118,7 +130,7 @@ __device__ __forceinline__ void item_body(const Params &p, int item, int lane, c
             if constexpr (STORE) st4<STORE>(row + 4 * lane + 256 * j, qf[j]); else if (qf[j][0] == 12345.678f) row[lane] = qf[j][1];
         }
     }
-    if constexpr (PIPE == 1 || PIPE == 2) {
+    if constexpr (PIPE == 1 || PIPE == 2 || PIPE == 4) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -139,13 +151,13 @@ __global__ __launch_bounds__((MAP >= 6) ? 1024 : 256) __attribute__((amdgpu_wave
     const int wib = threadIdx.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wib);
     const int n_waves = gridDim.x * wpb;
-    double zr[4][4], zi[4][4];
+    real_t zr[4][4], zi[4][4];
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int i = 4 * lane + 256 * j + e;
-            zr[j][e] = p.ztab[2 * i]; zi[j][e] = p.ztab[2 * i + 1];
+            zr[j][e] = (real_t)p.ztab[2 * i]; zi[j][e] = (real_t)p.ztab[2 * i + 1];
         }
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -233,7 +245,37 @@ __global__ __launch_bounds__((MAP >= 6) ? 1024 : 256) __attribute__((amdgpu_wave
         const int st = p.coop_stride;
         const int blk = blockIdx.x / st, o = blockIdx.x - blk * st;
         const int first = blk * st * wpb + o + st * wib;
+        // COOP 4: the two halves of the workgroup run half an item apart (two barriers per item, the second half one barrier
+        // behind): at every barrier one half starts its stores while the other is inside pass 1
+        const bool late = (COOP == 4) && (wib >= wpb / 2);
+        if (late) __builtin_amdgcn_s_barrier();
         for (int item = first; item < p.n_items; item += n_waves) item_body<ARITH, STORE, PIPE, 0, PK, COOP>(p, item, lane, zr, zi, held, held_row);
+        if (COOP == 4 && !late) __builtin_amdgcn_s_barrier();
+    } else if constexpr (MAP == 12) {
+        // pairs: a wave computes rows r and r + stride one after the other, keeps both in registers and writes them together,
+        // chunk-major (the same KiB of both rows back to back); no synchronisation between waves
+        const int st = p.coop_stride;
+        const int n_pairs = p.n_items / 2;
+        for (int pr = wave; pr < n_pairs; pr += n_waves) {
+            const int blk = pr / st, o = pr - blk * st;
+            const int r0 = blk * 2 * st + o;
+            float first_row[4][4];
+            item_body<ARITH, STORE, 4, 0, PK, 0>(p, r0, lane, zr, zi, held, held_row);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) first_row[j][e] = held[j][e];
+            item_body<ARITH, STORE, 4, 0, PK, 0>(p, r0 + st, lane, zr, zi, held, held_row);
+            if constexpr (STORE != 0) {
+                float *ra = p.spec + (size_t)r0 * 1024, *rb = p.spec + (size_t)(r0 + st) * 1024;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    st4<STORE>(ra + 4 * lane + 256 * j, first_row[j]);
+                    st4<STORE>(rb + 4 * lane + 256 * j, held[j]);
+                }
+            }
+        }
+        held_row = nullptr;
     } else if constexpr (MAP == 8) {
         const int per = (p.n_items + gridDim.x - 1) / gridDim.x;
         for (int t = wib; t < per; t += wpb) {
@@ -327,7 +369,112 @@ __global__ __launch_bounds__(256) void group_store_kernel(float *__restrict__ ou
     }
 }
 
+// Producer / consumer inside one 16-wave workgroup per CU: NC computing waves put their dB rows into an LDS generation buffer
+// (double-buffered), NW = 16 - NC writer waves -- one or more per SIMD -- drain the previous generation to HBM meanwhile: chunk-major
+// over the generation's rows, which are `stride` rows apart (the page-sharing rows written together, by waves that do nothing
+// else and may block at their stores as long as they like).  One workgroup barrier per generation.
+template <int ARITH, int STORE, int NC>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void pc_kernel(Params p)
+{
+    constexpr int NW = 16 - NC;
+    __shared__ f4 buf[2][NC][256];                      // NC x 4 KiB per generation
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int st = p.coop_stride;
+    const int blk = blockIdx.x / st, off = blockIdx.x - blk * st;
+    const int per_gen = gridDim.x * NC;
+    const int n_gen = (p.n_items + per_gen - 1) / per_gen;
+    const int first = blk * st * NC + off;              // + st * row_in_generation + g * per_gen
+    if (wib < NC) {
+        double zr[4][4], zi[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = 4 * lane + 256 * j + e;
+                zr[j][e] = p.ztab[2 * i]; zi[j][e] = p.ztab[2 * i + 1];
+            }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) asm volatile("" :: "v"(zr[j][e]), "v"(zi[j][e]));
+        for (int g = 0; g < n_gen; g++) {
+            const int item = first + st * wib + g * per_gen;
+            if (item < p.n_items) {
+                double c[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) c[k] = p.coef[(size_t)item * 8 + k];
+                float qf[4][4], cm[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if constexpr (ARITH) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const double cs = zr[j][e], sn = zi[j][e];
+                            const double A = fma(fma(fma(c[3], cs, c[2]), cs, c[1]), cs, c[0]);
+                            double B = fma(fma(c[6], cs, c[5]), cs, c[4]);
+#pragma unroll
+                            for (int x = 0; x < XTRA; x++) B = fma(B, sn, c[7]);
+                            qf[j][e] = (float)fma(sn, B, A);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) qf[j][e] = (float)c[e] + lane;
+                    }
+                    cm[j] = fminf(fminf(qf[j][0], qf[j][1]), fminf(qf[j][2], qf[j][3]));
+                }
+                float mn = fminf(fminf(cm[0], cm[1]), fminf(cm[2], cm[3]));
+                if constexpr (ARITH) mn = wave_min(mn);
+                const float inv = ARITH ? __builtin_amdgcn_rcpf(mn) * 1.0000002f : 1.0f;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    f4 d;
+                    d.x = ARITH ? -3.0103f * __log2f(qf[j][0] * inv) : qf[j][0];
+                    d.y = ARITH ? -3.0103f * __log2f(qf[j][1] * inv) : qf[j][1];
+                    d.z = ARITH ? -3.0103f * __log2f(qf[j][2] * inv) : qf[j][2];
+                    d.w = ARITH ? -3.0103f * __log2f(qf[j][3] * inv) : qf[j][3];
+                    buf[g & 1][wib][lane + 64 * j] = d;
+                }
+                if (lane == 0) { p.pk[(size_t)item] = 0.f; p.pk[(size_t)p.n_items + item] = mn; }
+            }
+            __syncthreads();
+        }
+    } else {
+        const int w = wib - NC;
+        for (int g = 0; g < n_gen; g++) {
+            __syncthreads();
+            if constexpr (STORE) {
+                // chunk-major: this writer takes the 1 KiB pieces q = w, w + NW, ... of the generation, piece q = chunk (q / NC)
+                // of row (q % NC): consecutive pieces are the same KiB of rows `stride` apart
+#pragma unroll 4
+                for (int q = w; q < 4 * NC; q += NW) {
+                    const int j = q / NC, r = q - j * NC;
+                    const int item = first + st * r + g * per_gen;
+                    if (item < p.n_items) {
+                        const f4 d = buf[g & 1][r][lane + 64 * j];
+                        __builtin_nontemporal_store(d, reinterpret_cast<f4 *>(p.spec + (size_t)item * 1024) + lane + 64 * j);
+                    }
+                }
+            }
+        }
+    }
+}
+
 struct Ctx { Params p[2]; unsigned *counters; };
+
+template <int ARITH, int STORE, int NC> double run_pc(Ctx &cx, int blocks)
+{
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int r = 0; r < 2; r++) hipLaunchKernelGGL((pc_kernel<ARITH, STORE, NC>), dim3(blocks), dim3(1024), 0, 0, cx.p[r & 1]);
+    CK(hipDeviceSynchronize());
+    const int reps = 8;
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL((pc_kernel<ARITH, STORE, NC>), dim3(blocks), dim3(1024), 0, 0, cx.p[r & 1]);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    return ms * 1e3 / reps;
+}
 
 template <int G, bool CM, bool SLEEP> double run_group(Ctx &cx, int wpb, int blocks, int stride)
 {
@@ -545,6 +692,96 @@ int main(int argc, char **argv)
             CROW("both 16x16, barrier before pass 2", 1, 0, 1, 16);
             CROW("both 2x16, barrier before pass 2", 1, 0, 1, 2);
             CROW("stores only 4x16, barrier", 0, 0, 1, 4);
+        }
+    }
+    if (want("r8")) {
+        const int strides[] = {4, 8, 16};
+        printf("XTRA = %d extra FMA64 per angle; workgroup-cooperative rows (map 10), columns: stride = 4 8 16\n", XTRA);
+#define CROW8(label, A_, S_, PI_, CO_, wpb_) do { printf("%-64s", label); for (int st : strides) { cx.p[0].coop_stride = cx.p[1].coop_stride = st; \
+            printf(" %6.1f", run<A_, S_, 0, PI_, 10, 1, CO_>(cx, wpb_, cus * 16 / wpb_)); fflush(stdout); } printf("\n"); } while (0)
+        for (int rep = 0; rep < 2; rep++) {
+            printf("-- repetition %d\n", rep);
+            ROWG("both, static 4x16 (shipped mapping)", (std::vector<Geo>{{4, 16, 0}}), 1, 1, 0, 0, 0, 1);
+            ROWG("arith only, static 4x16", (std::vector<Geo>{{4, 16, 0}}), 1, 0, 0, 0, 0, 1);
+            CROW8("arith only 16x16, barrier before pass 2", 1, 0, 0, 1, 16);
+            CROW8("stores only 16x16, barrier before pass 2", 0, 1, 0, 1, 16);
+            CROW8("both 16x16, barrier before pass 2", 1, 1, 0, 1, 16);
+            CROW8("both 16x16, row held, stores in next pass 1, barrier at item start", 1, 1, 1, 3, 16);
+            CROW8("both 16x16, row held, stores over next item, barrier at item start", 1, 1, 2, 3, 16);
+            CROW8("both 16x16, row held, stores in next pass 1, barrier before pass 2", 1, 1, 1, 1, 16);
+            CROW8("both 16x16, four stores at item end behind a barrier", 1, 1, 3, 2, 16);
+            CROW8("both 8x16, row held, stores in next pass 1, barrier at item start", 1, 1, 1, 3, 8);
+            CROW8("both 16x16, row held, stores in next pass 1, no barrier", 1, 1, 1, 0, 16);
+        }
+    }
+    if (want("r9")) {
+        const int strides[] = {1, 4, 8, 16, 32};
+        printf("XTRA = %d; producer/consumer in one 16-wave workgroup per CU (NC computing + 16-NC writer waves); columns: stride = 1 4 8 16 32\n", XTRA);
+#define PROW(label, A_, S_, NC_) do { printf("%-60s", label); for (int st : strides) { cx.p[0].coop_stride = cx.p[1].coop_stride = st; \
+            printf(" %6.1f", run_pc<A_, S_, NC_>(cx, cus / st * st)); fflush(stdout); } printf("\n"); } while (0)
+        for (int rep = 0; rep < 2; rep++) {
+            printf("-- repetition %d\n", rep);
+            ROWG("both, static 4x16 (shipped mapping)", (std::vector<Geo>{{4, 16, 0}}), 1, 1, 0, 0, 0, 1);
+            ROWG("arith only, static 4x16", (std::vector<Geo>{{4, 16, 0}}), 1, 0, 0, 0, 0, 1);
+            ROWG("arith only, static 4x12", (std::vector<Geo>{{4, 12, 0}}), 1, 0, 0, 0, 0, 1);
+            PROW("12 + 4: arith only (rows into LDS, no HBM stores)", 1, 0, 12);
+            PROW("12 + 4: stores only", 0, 1, 12);
+            PROW("12 + 4: both", 1, 1, 12);
+            PROW("14 + 2: both", 1, 1, 14);
+            PROW("8 + 8: both", 1, 1, 8);
+            PROW("15 + 1: both", 1, 1, 15);
+        }
+    }
+    if (want("r10")) {
+        const int strides[] = {4, 8, 16};
+        printf("XTRA = %d; workgroup-cooperative rows (map 10), columns: stride = 4 8 16\n", XTRA);
+        for (int rep = 0; rep < 2; rep++) {
+            printf("-- repetition %d\n", rep);
+            ROWG("both, static 4x16 (shipped mapping)", (std::vector<Geo>{{4, 16, 0}}), 1, 1, 0, 0, 0, 1);
+            ROWG("both, static 1x12", (std::vector<Geo>{{1, 12, 0}}), 1, 1, 0, 0, 0, 1);
+            CROW8("both 4x16, barrier before pass 2", 1, 1, 0, 1, 4);
+            CROW8("both 8x16, barrier before pass 2", 1, 1, 0, 1, 8);
+            CROW8("both 16x16, barrier before pass 2", 1, 1, 0, 1, 16);
+            CROW8("both 16x16, halves in anti-phase (2 barriers per item)", 1, 1, 0, 4, 16);
+            CROW8("both 8x16, halves in anti-phase", 1, 1, 0, 4, 8);
+            CROW8("arith only 16x16, halves in anti-phase", 1, 0, 0, 4, 16);
+            CROW8("stores only 16x16, halves in anti-phase", 0, 1, 0, 4, 16);
+        }
+    }
+    if (want("r11")) {
+        const int strides[] = {1, 4, 8, 16, 32};
+        printf("XTRA = %d; pairs of rows per wave (map 12), no barrier; columns: stride = 1 4 8 16 32\n", XTRA);
+#define PAIRROW(label, A_, S_, wpb_, wpc_) do { printf("%-50s", label); for (int st : strides) { cx.p[0].coop_stride = cx.p[1].coop_stride = st; \
+            printf(" %6.1f", run<A_, S_, 0, 0, 12, 1, 0>(cx, wpb_, cus * wpc_ / wpb_)); fflush(stdout); } printf("\n"); } while (0)
+        for (int rep = 0; rep < 2; rep++) {
+            printf("-- repetition %d\n", rep);
+            ROWG("both, static 4x16 (shipped mapping)", (std::vector<Geo>{{4, 16, 0}}), 1, 1, 0, 0, 0, 1);
+            ROWG("both, static 1x12", (std::vector<Geo>{{1, 12, 0}}), 1, 1, 0, 0, 0, 1);
+            ROWG("both, static 4x12", (std::vector<Geo>{{4, 12, 0}}), 1, 1, 0, 0, 0, 1);
+            PAIRROW("pairs, both 4x16", 1, 1, 4, 16);
+            PAIRROW("pairs, both 1x16", 1, 1, 1, 16);
+            PAIRROW("pairs, both 4x12", 1, 1, 4, 12);
+            PAIRROW("pairs, both 1x12", 1, 1, 1, 12);
+            PAIRROW("pairs, arith only 4x16", 1, 0, 4, 16);
+            PAIRROW("pairs, stores only 4x16", 0, 1, 4, 16);
+        }
+    }
+    if (want("r12")) {
+#ifdef FP32
+        printf("arithmetic in FLOAT, XTRA = %d\n", XTRA);
+#else
+        printf("arithmetic in DOUBLE, XTRA = %d\n", XTRA);
+#endif
+        const int strides[] = {8};
+        for (int rep = 0; rep < 3; rep++) {
+            printf("-- repetition %d\n", rep);
+            ROWG("arith only, static 4x16", (std::vector<Geo>{{4, 16, 0}}), 1, 0, 0, 0, 0, 1);
+            ROWG("stores only, static 4x16", (std::vector<Geo>{{4, 16, 0}}), 0, 1, 0, 0, 0, 1);
+            ROWG("both, static 4x16 (shipped mapping)", (std::vector<Geo>{{4, 16, 0}}), 1, 1, 0, 0, 0, 1);
+            PAIRROW("pairs stride 8, arith only 4x16", 1, 0, 4, 16);
+            PAIRROW("pairs stride 8, stores only 4x16", 0, 1, 4, 16);
+            PAIRROW("pairs stride 8, both 4x16", 1, 1, 4, 16);
+            CROW8("coop 16x16 stride 8, barrier before pass 2, both", 1, 1, 0, 1, 16);
         }
     }
     if (want("ticket")) {        // (3 ms per launch: ~11.5 ns per returning atomic on one line, whatever the address count)
