@@ -2,6 +2,7 @@
 #include "common.hpp"
 
 #include <atomic>
+#include <mutex>
 
 namespace doa {
 
@@ -41,21 +42,29 @@ int ensure_device(int *device_out)
 // worse than streams mapped onto a populated pool: four pipeline chains on the first four streams of a process run at
 // 32.6-32.9 us per 4096-snapshot step, on any later four at 26.0-26.8 (tools/lab/lanes_sweep.py with PRE_STREAMS = 0 / 3+,
 // same box, whoever creates the streams).  So the pool is populated once per device, before any handle creates a stream:
-// four throw-away streams, one trivial operation each; they stay alive for the life of the process (64 bytes of device memory).
+// four throw-away streams, one trivial operation each; they stay alive for the life of the process (64 bytes of device
+// memory) -- whether the hardware queues would outlive their streams is not documented, so the streams are kept.
+// This is an effect on the HOST PROCESS (include/doa_hip.h and INTEGRATION.md say so); DOA_HIP_NO_QUEUE_PRIMING=1 in the
+// environment switches it off.  One thread primes a device; others creating handles on it meanwhile wait for it (the point
+// is that no lane stream exists before the pool is populated), and a failure is not remembered as success.
 void prime_hw_queues(int dev)
 {
-    static std::atomic<unsigned> primed{0};
-    if (dev < 0 || dev >= 32) return;
-    const unsigned bit = 1u << dev;
-    if (primed.fetch_or(bit) & bit) return;
+    static const bool off = [] { const char *e = getenv("DOA_HIP_NO_QUEUE_PRIMING"); return e && *e && *e != '0'; }();
+    if (off || dev < 0 || dev >= 64) return;
+    static std::mutex mtx;
+    static bool primed[64] = {};
+    std::lock_guard<std::mutex> lock(mtx);
+    if (primed[dev]) return;
     void *scratch = nullptr;
     if (hipMalloc(&scratch, 64) != hipSuccess) { (void)hipGetLastError(); return; }
+    int made = 0;
     for (int i = 0; i < 4; i++) {
         hipStream_t s = nullptr;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
-        (void)hipMemsetAsync(scratch, 0, 64, s);
-        (void)hipStreamSynchronize(s);
+        if (hipMemsetAsync(scratch, 0, 64, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); break; }
+        made++;
     }
+    primed[dev] = (made == 4);
 }
 
 int cu_count()

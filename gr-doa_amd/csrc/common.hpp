@@ -11,6 +11,7 @@
 #include <new>
 
 #include "../../include/doa_hip.h"
+#include "../../include/doa_hip_test.h"
 
 namespace doa {
 

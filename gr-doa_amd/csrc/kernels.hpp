@@ -35,6 +35,10 @@ inline bool music_uses_cheb(int N, int bits) { return N <= 4 && bits == 64; }
 constexpr int kChebRecord = 8;      // doubles per item
 // diagnostics: items that left the signal-subspace fast path of K2+K3 for the Jacobi fall-back since the last reset
 long long evd_fallback_count(bool reset);
+// the calling thread's current device's counter (allocated on first use; nullptr if that fails) and, for the tests, the device
+// an allocation lives on
+unsigned long long *evd_fallback_counter();
+int evd_fallback_counter_device(const void *p);
 // calibrate_lin_array (calibrate.hip): d_pilot = N float2 (pilot steering vector), d_out = n_items*N float2
 int launch_calibrate(int N, int n_items, const void *d_R, const void *d_pilot, void *d_out, int bits, hipStream_t st);
 // K4: spectrum scan in float (bits == 32, float coefficient records) or double (bits == 64, double

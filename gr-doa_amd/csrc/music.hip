@@ -257,6 +257,14 @@ long long doa_hip_evd_fallback_count(int reset)
     return doa::evd_fallback_count(reset != 0);
 }
 
+int doa_hip_evd_fallback_counter_device_debug(void)
+{
+    doa::clear_error();
+    int dev = 0;
+    if (doa::ensure_device(&dev) != DOA_OK) return -1;
+    return doa::evd_fallback_counter_device(doa::evd_fallback_counter());
+}
+
 int doa_MUSIC_lin_array_set_internal_precision(doa_MUSIC_lin_array_t *h, int bits)
 {
     doa::clear_error();

@@ -7,6 +7,7 @@
 // (covariances, coefficient records, spectra) stay in HBM-resident buffers owned by the handle
 // unless the caller asks for them.
 #include "kernels.hpp"
+#include "pipeline_lanes.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -33,19 +34,10 @@ struct doa_music_pipeline {
     doa::DevBuf d_in[2], d_res;
     doa::DevBuf d_work[2];          // K1's piece sums (overlapping windows), one per copy/compute lane
     doa::PinnedBuf h_stage;         // scheduler-sized calls: one page-locked staging buffer, one copy each way
-    int fail_chunk = -1;            // doa_music_pipeline_inject_failure: one-shot; host-pointer entry (chunk) or batches entry (batch) (tests)
-    // doa_music_pipeline_work_dev_batches: the library's own overlap lanes (streams + one workspace each)
-    struct Lane {
-        hipStream_t st = nullptr;
-        bool own_stream = true;         // false: adopted from the caller (doa_music_pipeline_set_lane_streams)
-        hipEvent_t done = nullptr;
-        doa::DevBuf coef, cheb, cov, spec, work, scratch;
-    };
-    static constexpr int kMaxLanes = 8;
-    Lane lanes[kMaxLanes];
-    int n_lanes = 4;
-    int next_lane = 0;              // lanes keep rotating across calls
-    hipEvent_t fork_ev = nullptr;
+    int fail_chunk = -1;            // doa_music_pipeline_inject_failure, host-pointer entry: one-shot, cleared by every call (tests)
+    // doa_music_pipeline_work_dev_batches: the library's own overlap lanes (pipeline_lanes.hpp); a lane's buffers:
+    enum { kCoef = 0, kCheb, kCov, kSpec, kWork, kScratch };
+    doa::PipeLanes lanes;
 };
 
 // what one K1 -> EVD -> scan chain needs besides its inputs and outputs
@@ -167,12 +159,7 @@ void doa_music_pipeline_destroy(doa_music_pipeline_t *h)
     for (auto &b : h->d_in) b.release();
     for (auto st : h->hst)
         if (st) (void)hipStreamDestroy(st);
-    for (auto &l : h->lanes) {
-        l.coef.release(); l.cheb.release(); l.cov.release(); l.spec.release(); l.work.release(); l.scratch.release();
-        if (l.done) (void)hipEventDestroy(l.done);
-        if (l.st && l.own_stream) (void)hipStreamDestroy(l.st);
-    }
-    if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+    h->lanes.release();
     delete h;
 }
 
@@ -227,12 +214,10 @@ int doa_music_pipeline_work_dev(doa_music_pipeline_t *h, int noutput_items, cons
 int doa_music_pipeline_set_lanes(doa_music_pipeline_t *h, int n_lanes)
 {
     doa::clear_error();
-    if (!h || n_lanes < 1 || n_lanes > doa_music_pipeline::kMaxLanes) {
-        doa::set_error("music_pipeline_set_lanes: need 1 <= n_lanes <= %d", doa_music_pipeline::kMaxLanes);
+    if (!h || h->lanes.set_count(n_lanes) != DOA_OK) {
+        doa::set_error("music_pipeline_set_lanes: need 1 <= n_lanes <= %d", doa::PipeLanes::kMaxLanes);
         return DOA_ERR_INVALID_ARG;
     }
-    h->n_lanes = n_lanes;
-    h->next_lane = 0;
     return DOA_OK;
 }
 
@@ -257,103 +242,62 @@ int doa_music_pipeline_work_dev_batches(doa_music_pipeline_t *h, int n_batches, 
         }
     if (n_batches == 0 || noutput_items == 0) return 0;
     if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
-    hipStream_t caller = static_cast<hipStream_t>(hip_stream);
     const int N = h->N;
-    if (h->n_lanes == 1 && hip_stream != DOA_STREAM_DETACHED) {     // nothing to overlap: the caller's stream itself, no events
+    const int fail_at = h->lanes.fail_batch;
+    h->fail_chunk = -1;                                          // (the test aid is one-shot for whichever entry comes next)
+    if (h->lanes.n_lanes == 1 && hip_stream != DOA_STREAM_DETACHED) {     // nothing to overlap: the caller's stream itself, no events
+        hipStream_t caller = static_cast<hipStream_t>(hip_stream);
+        h->lanes.fail_batch = -1;
         for (int b = 0; b < n_batches; b++) {
+            if (fail_at == b) {
+                doa::set_error("music_pipeline_work_dev_batches: injected failure in batch %d", b);
+                (void)hipStreamSynchronize(caller);              // the contract of an error return: nothing of the call still runs
+                return DOA_ERR_HIP;
+            }
             void *cov = (d_cov_out && d_cov_out[b]) ? d_cov_out[b] : h->d_cov.p;
             const int rc = run_dev(h, noutput_items, d_input_items + (size_t)b * N, cov, d_spectrum_out ? d_spectrum_out[b] : nullptr,
                                    d_max_out[b], d_argmax_out[b], 0, caller);
-            if (rc < 0) return rc;
+            if (rc < 0) { (void)hipStreamSynchronize(caller); return rc; }
         }
         return n_batches * noutput_items;
     }
-    // lanes: streams, events and workspaces, created on first use
     const bool dbl = (h->bits == 64);
-    const bool detached = (hip_stream == DOA_STREAM_DETACHED);
     bool need_cov = !d_cov_out, need_spec = !d_spectrum_out;
     for (int b = 0; b < n_batches && !(need_cov && need_spec); b++) {
         if (d_cov_out && !d_cov_out[b]) need_cov = true;
         if (d_spectrum_out && !d_spectrum_out[b]) need_spec = true;
     }
-    if (!detached && !h->fork_ev) DOA_HIP_TRY(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     const size_t work_bytes = doa::autocorrelate_workspace_bytes(N, h->K, h->ovl, h->max_batch);
-    const int L = h->n_lanes;
-    for (int l = 0; l < L; l++) {
-        auto &ln = h->lanes[l];
-        if (!ln.st) { DOA_HIP_TRY(hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking)); ln.own_stream = true; }
-        if (!detached && !ln.done) DOA_HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
-        int rc = ln.coef.reserve((size_t)h->max_batch * doa::coef_stride(N) * (dbl ? sizeof(double) : sizeof(float)));
-        if (rc == DOA_OK && doa::music_uses_cheb(N, h->bits)) rc = ln.cheb.reserve((size_t)h->max_batch * doa::kChebRecord * sizeof(double));
-        if (rc == DOA_OK && need_cov) rc = ln.cov.reserve((size_t)h->max_batch * N * N * sizeof(float2));
-        if (rc == DOA_OK && need_spec) rc = ln.spec.reserve((size_t)h->max_batch * h->peaks.L * sizeof(float));
-        if (rc == DOA_OK && work_bytes) rc = ln.work.reserve(work_bytes);
-        if (rc != DOA_OK) return rc;
-    }
-    // Batch b of this call runs its K1 -> EVD -> scan chain on lane (next_lane + b) % L, in order on that lane; the
-    // rotation carries over from call to call.  Attached to a stream, the call forks (every lane waits for what the caller's
-    // stream holds now: one event) and joins (the caller's stream waits for every lane: one event per lane) ONCE, whatever
-    // n_batches is.  Cross-stream events are expensive on this runtime (~80 us per fork + join, and an event per batch
-    // degrades the lanes to the serial rate -- measured), which is why there is no finer-grained schedule
-    // here and why the detached form exists.
-    const int lane0 = h->next_lane % L;
-    h->next_lane = (lane0 + n_batches) % L;
-    const int used = n_batches < L ? n_batches : L;
-    if (!detached) {
-        DOA_HIP_TRY(hipEventRecord(h->fork_ev, caller));
-        for (int u = 0; u < used; u++) DOA_HIP_TRY(hipStreamWaitEvent(h->lanes[(lane0 + u) % L].st, h->fork_ev, 0));
-    }
-    int rc = DOA_OK;
-    for (int b = 0; b < n_batches && rc >= 0; b++) {
-        if (h->fail_chunk == b) {                          // doa_music_pipeline_inject_failure (tests), one-shot
-            h->fail_chunk = -1;
-            doa::set_error("music_pipeline_work_dev_batches: injected failure in batch %d", b);
-            rc = DOA_ERR_HIP;
-            break;
-        }
-        auto &ln = h->lanes[(lane0 + b) % L];
-        PipeWs ws;
-        ws.coef = ln.coef.p; ws.cheb = ln.cheb.p; ws.spec_scratch = ln.spec.p; ws.work = ln.work.p; ws.scratch = &ln.scratch; ws.scratch_item_off = 0;
-        void *cov = (d_cov_out && d_cov_out[b]) ? d_cov_out[b] : ln.cov.p;
-        rc = run_ws(h, noutput_items, d_input_items + (size_t)b * N, cov, d_spectrum_out ? d_spectrum_out[b] : nullptr, d_max_out[b],
-                    d_argmax_out[b], ws, ln.st);
-    }
-    // the join happens whatever the enqueue loop returned: nothing may stay detached from the caller's stream
-    for (int u = 0; u < used && !detached; u++) {
-        auto &ln = h->lanes[(lane0 + u) % L];
-        const hipError_t e1 = hipEventRecord(ln.done, ln.st);
-        const hipError_t e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(caller, ln.done, 0) : e1;
-        if (e2 != hipSuccess && rc >= 0) { doa::set_error("music_pipeline_work_dev_batches: join failed: %s", hipGetErrorString(e2)); rc = DOA_ERR_HIP; }
-    }
-    if (rc < 0) {
-        // an error return means "nothing of this call is still running": what the lanes were handed before the failing
-        // launch is waited for here (detached callers included, who would otherwise have to know that they must still
-        // synchronise a call that failed)
-        const std::string msg = doa_last_error();
-        for (int u = 0; u < used; u++) (void)hipStreamSynchronize(h->lanes[(lane0 + u) % L].st);
-        doa::set_error("%s", msg.c_str());
+    using H = doa_music_pipeline;
+    auto prepare = [&](doa::PipeLane &ln) -> int {
+        int rc = ln.buf[H::kCoef].reserve((size_t)h->max_batch * doa::coef_stride(N) * (dbl ? sizeof(double) : sizeof(float)));
+        if (rc == DOA_OK && doa::music_uses_cheb(N, h->bits)) rc = ln.buf[H::kCheb].reserve((size_t)h->max_batch * doa::kChebRecord * sizeof(double));
+        if (rc == DOA_OK && need_cov) rc = ln.buf[H::kCov].reserve((size_t)h->max_batch * N * N * sizeof(float2));
+        if (rc == DOA_OK && need_spec) rc = ln.buf[H::kSpec].reserve((size_t)h->max_batch * h->peaks.L * sizeof(float));
+        if (rc == DOA_OK && work_bytes) rc = ln.buf[H::kWork].reserve(work_bytes);
         return rc;
-    }
-    return n_batches * noutput_items;
+    };
+    auto launch = [&](int b, doa::PipeLane &ln) -> int {
+        PipeWs ws;
+        ws.coef = ln.buf[H::kCoef].p; ws.cheb = ln.buf[H::kCheb].p; ws.spec_scratch = ln.buf[H::kSpec].p; ws.work = ln.buf[H::kWork].p;
+        ws.scratch = &ln.buf[H::kScratch]; ws.scratch_item_off = 0;
+        void *cov = (d_cov_out && d_cov_out[b]) ? d_cov_out[b] : ln.buf[H::kCov].p;
+        return run_ws(h, noutput_items, d_input_items + (size_t)b * N, cov, d_spectrum_out ? d_spectrum_out[b] : nullptr, d_max_out[b],
+                      d_argmax_out[b], ws, ln.st);
+    };
+    const int rc = h->lanes.run_batches("music_pipeline_work_dev_batches", n_batches, hip_stream, prepare, launch);
+    return rc < 0 ? rc : n_batches * noutput_items;
 }
 
 int doa_music_pipeline_set_lane_streams(doa_music_pipeline_t *h, int n_lanes, void *const *hip_streams)
 {
     doa::clear_error();
-    if (!h || n_lanes < 1 || n_lanes > doa_music_pipeline::kMaxLanes || !hip_streams) {
-        doa::set_error("music_pipeline_set_lane_streams: need 1 <= n_lanes <= %d and the streams", doa_music_pipeline::kMaxLanes);
+    if (!h || n_lanes < 1 || n_lanes > doa::PipeLanes::kMaxLanes || !hip_streams) {
+        doa::set_error("music_pipeline_set_lane_streams: need 1 <= n_lanes <= %d and the streams", doa::PipeLanes::kMaxLanes);
         return DOA_ERR_INVALID_ARG;
     }
     if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
-    for (int l = 0; l < n_lanes; l++) {
-        auto &ln = h->lanes[l];
-        if (ln.st) { (void)hipStreamSynchronize(ln.st); if (ln.own_stream) (void)hipStreamDestroy(ln.st); }
-        ln.st = static_cast<hipStream_t>(hip_streams[l]);
-        ln.own_stream = false;
-    }
-    h->n_lanes = n_lanes;
-    h->next_lane = 0;
-    return DOA_OK;
+    return h->lanes.adopt(n_lanes, hip_streams);
 }
 
 int doa_music_pipeline_synchronize(doa_music_pipeline_t *h)
@@ -361,9 +305,7 @@ int doa_music_pipeline_synchronize(doa_music_pipeline_t *h)
     doa::clear_error();
     if (!h) { doa::set_error("music_pipeline_synchronize: bad arguments"); return DOA_ERR_INVALID_ARG; }
     if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
-    for (int l = 0; l < doa_music_pipeline::kMaxLanes; l++)
-        if (h->lanes[l].st) DOA_HIP_TRY(hipStreamSynchronize(h->lanes[l].st));
-    return DOA_OK;
+    return h->lanes.synchronize();
 }
 
 int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const void *const *input_items, void *cov_out,
@@ -438,7 +380,7 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
                 return DOA_OK;
             };
             rc = staged();
-            h->fail_chunk = -1;
+            h->fail_chunk = -1; h->lanes.fail_batch = -1;
             const hipError_t se = hipStreamSynchronize(st);
             if (rc < 0) return rc;
             if (se != hipSuccess) { doa::set_error("music_pipeline_work: %s", hipGetErrorString(se)); return DOA_ERR_HIP; }
@@ -499,7 +441,7 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
         rc = enqueue_chunk(s0, n, h->hst[lane]);
         if (rc < 0) break;
     }
-    h->fail_chunk = -1;
+    h->fail_chunk = -1; h->lanes.fail_batch = -1;
     for (auto st : h->hst) {
         const hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess && rc >= 0) { doa::set_error("music_pipeline_work: %s", hipGetErrorString(e)); rc = DOA_ERR_HIP; }
@@ -511,7 +453,8 @@ int doa_music_pipeline_inject_failure(doa_music_pipeline_t *h, int chunk_index)
 {
     doa::clear_error();
     if (!h || chunk_index < -1) { doa::set_error("music_pipeline_inject_failure: bad arguments"); return DOA_ERR_INVALID_ARG; }
-    h->fail_chunk = chunk_index;
+    h->fail_chunk = chunk_index;            // whichever entry is called next consumes it: the host entry (chunk index) ...
+    h->lanes.fail_batch = chunk_index;      // ... or the batches entry (batch index); both clear both
     return DOA_OK;
 }
 
@@ -522,9 +465,7 @@ int doa_music_pipeline_lanes_idle(doa_music_pipeline_t *h)
     if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
     for (auto st : h->hst)
         if (st && hipStreamQuery(st) != hipSuccess) return 0;
-    for (int l = 0; l < doa_music_pipeline::kMaxLanes; l++)
-        if (h->lanes[l].st && hipStreamQuery(h->lanes[l].st) != hipSuccess) return 0;
-    return 1;
+    return h->lanes.idle() ? 1 : 0;
 }
 
 int doa_music_pipeline_set_internal_precision(doa_music_pipeline_t *h, int bits)

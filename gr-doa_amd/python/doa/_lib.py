@@ -55,7 +55,7 @@ lib = C.CDLL(LIB_PATH)
 _vp = C.c_void_p
 _vpp = C.POINTER(C.c_void_p)
 
-# name -> (restype, argtypes); mirrors include/doa_hip.h one to one
+# name -> (restype, argtypes); mirrors include/doa_hip.h and include/doa_hip_test.h one to one
 SIGNATURES = {
     "doa_last_error": (C.c_char_p, []),
     "doa_hip_abi_version": (C.c_int, []),
@@ -124,6 +124,20 @@ SIGNATURES = {
     "doa_sim_source_tell": (C.c_longlong, [_vp]),
     "doa_sim_source_work": (C.c_int, [_vp, C.c_int, _vpp]),
     "doa_sim_source_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vp]),
+    "doa_root_pipeline_create": (_vp, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]),
+    "doa_root_pipeline_destroy": (None, [_vp]),
+    "doa_root_pipeline_fuse_antenna_correction": (C.c_int, [_vp, _vp]),
+    "doa_root_pipeline_work_dev": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp, _vp, _vp]),
+    "doa_root_pipeline_work_dev_batches": (C.c_int, [_vp, C.c_int, C.c_int, _vpp, _vpp, _vpp, _vpp, _vp]),
+    "doa_root_pipeline_synchronize": (C.c_int, [_vp]),
+    "doa_root_pipeline_set_lanes": (C.c_int, [_vp, C.c_int]),
+    "doa_root_pipeline_set_lane_streams": (C.c_int, [_vp, C.c_int, _vpp]),
+    "doa_root_pipeline_set_internal_precision": (C.c_int, [_vp, C.c_int]),
+    "doa_root_pipeline_work": (C.c_int, [_vp, C.c_int, _vpp, _vp, _vp]),
+    # include/doa_hip_test.h (diagnostics, profiling, fault injection: the test suite's entry points)
+    "doa_root_pipeline_inject_failure": (C.c_int, [_vp, C.c_int]),
+    "doa_root_pipeline_lanes_idle": (C.c_int, [_vp]),
+    "doa_hip_evd_fallback_counter_device_debug": (C.c_int, []),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

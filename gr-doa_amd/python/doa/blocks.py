@@ -481,6 +481,105 @@ class music_pipeline(_Block):
             none if spectrum_out is None else _vp(spectrum_out), _vp(max_out), _vp(argmax_out)))
 
 
+class root_pipeline(_Block):
+    """autocorrelate -> rootMUSIC_linear_array on device-resident streams (the wiring of
+    apps/run_RootMUSIC_lin_array_simulation.grc) as ONE handle: the Root-MUSIC branch of the hot path with the same entry
+    points as music_pipeline (work_dev, work_dev_batches over the handle's lanes, detached form, host-buffer work).
+    Not a block of the reference."""
+
+    _destroy = staticmethod(lib.doa_root_pipeline_destroy)
+    _set_precision = staticmethod(lib.doa_root_pipeline_set_internal_precision)
+
+    def __init__(self, inputs, snapshot_size, overlap_size, avg_method, norm_spacing, num_targets, max_batch=4096):
+        super().__init__()
+        self.inputs, self.snapshot_size, self.overlap_size = int(inputs), int(snapshot_size), int(overlap_size)
+        self.avg_method, self.norm_spacing = int(avg_method), float(norm_spacing)
+        self.num_targets, self.max_batch = int(num_targets), int(max_batch)
+        self._h = check_handle(lib.doa_root_pipeline_create(self.inputs, self.snapshot_size, self.overlap_size, self.avg_method,
+                                                            self.norm_spacing, self.num_targets, self.max_batch), "root_pipeline")
+        # as a flowgraph block (gr::doa::root_music_pipeline of the C++ shells): N complex streams in; out0 = angles
+        self.in_sig = [(_C64, 1)] * self.inputs
+        self.out_sig = [(_F32, self.num_targets)]
+
+    def history(self) -> int:
+        return self.overlap_size + 1                          # as doa.autocorrelate (autocorrelate_impl.cc:56-57)
+
+    def forecast(self, noutput_items: int) -> int:
+        return (self.snapshot_size - self.overlap_size) * int(noutput_items)
+
+    def input_span(self, noutput_items) -> int:
+        n = int(noutput_items)
+        return 0 if n <= 0 else (n - 1) * (self.snapshot_size - self.overlap_size) + self.snapshot_size
+
+    def general_work(self, noutput_items, input_items, output_items):
+        """output_items = [angles [>=n, M]].  Returns (items produced, items consumed per input)."""
+        n, done = int(noutput_items), 0
+        S = self.snapshot_size - self.overlap_size
+        while done < n:
+            k = min(self.max_batch, n - done)
+            done += self.work(k, [a[done * S:] for a in input_items], output_items[0][done:done + k])
+        return done, self.forecast(done)
+
+    def fuse_antenna_correction(self, correction) -> None:
+        _fuse(lib.doa_root_pipeline_fuse_antenna_correction, self._h, correction, self.inputs)
+
+    def inject_failure(self, chunk_index: int) -> None:
+        """Test aid: the next work() / work_dev_batches() call fails in chunk / batch `chunk_index` (one-shot; -1 disarms)."""
+        check(lib.doa_root_pipeline_inject_failure(self._h, int(chunk_index)))
+
+    def lanes_idle(self) -> bool:
+        return bool(check(lib.doa_root_pipeline_lanes_idle(self._h)))
+
+    def work_dev(self, noutput_items, d_input_ptrs, d_cov_ptr, d_angles_ptr, d_status_ptr=None, stream=None) -> int:
+        return check(lib.doa_root_pipeline_work_dev(
+            self._h, int(noutput_items), ptr_array(d_input_ptrs), C.c_void_p(int(d_cov_ptr or 0)), C.c_void_p(int(d_angles_ptr)),
+            C.c_void_p(int(d_status_ptr or 0)), _stream_ptr(stream)))
+
+    def set_lanes(self, n_lanes: int) -> None:
+        check(lib.doa_root_pipeline_set_lanes(self._h, int(n_lanes)))
+
+    def set_lane_streams(self, streams) -> None:
+        self._lane_streams = list(streams)
+        check(lib.doa_root_pipeline_set_lane_streams(self._h, len(self._lane_streams),
+                                                     ptr_array([_stream_ptr(s).value or 0 for s in self._lane_streams])))
+
+    def synchronize(self) -> None:
+        check(lib.doa_root_pipeline_synchronize(self._h))
+
+    def work_dev_batches(self, noutput_items, d_input_ptrs, d_cov_ptrs, d_angles_ptrs, d_status_ptrs=None, stream=None) -> int:
+        return self.prepare_batches(noutput_items, d_input_ptrs, d_cov_ptrs, d_angles_ptrs, d_status_ptrs, stream)()
+
+    def prepare_batches(self, noutput_items, d_input_ptrs, d_cov_ptrs, d_angles_ptrs, d_status_ptrs=None, stream=None):
+        """The argument marshalling of work_dev_batches done once: returns a callable that makes the C call."""
+        nb = len(d_angles_ptrs)
+        flat = [p for b in d_input_ptrs for p in b] if nb and isinstance(d_input_ptrs[0], (list, tuple)) else list(d_input_ptrs)
+        assert len(flat) == nb * self.inputs
+        opt = lambda ptrs: None if ptrs is None else ptr_array([int(p or 0) for p in ptrs])
+        args = (self._h, nb, int(noutput_items), ptr_array(flat), opt(d_cov_ptrs), ptr_array(d_angles_ptrs), opt(d_status_ptrs),
+                _stream_ptr(stream))
+        fn = lib.doa_root_pipeline_work_dev_batches
+        return lambda: check(fn(*args))
+
+    def work(self, noutput_items, input_items, angles_out, cov_out=None) -> int:
+        """Host buffers in, host buffers out (numpy): input_items[k] = complex64 stream k starting at its first history
+        sample; angles_out [>=n, M] float32; cov_out [>=n, N*N] complex64 is optional.  Raises DoaError(DOA_ERR_NUMERIC) when
+        an item has no root inside the unit circle (the outputs of the other items are valid)."""
+        n = int(noutput_items)
+        span = self.input_span(n)
+        arrs = []
+        for k in range(self.inputs):
+            a = np.ascontiguousarray(input_items[k], dtype=_C64)
+            if a.shape[0] < span:
+                raise ValueError(f"input {k}: {a.shape[0]} samples, need {span}")
+            arrs.append(a)
+        for o, dt, per in ((angles_out, _F32, self.num_targets), (cov_out, _C64, self.inputs ** 2)):
+            if o is not None:
+                assert o.dtype == dt and o.flags.c_contiguous and o.size >= n * per
+        none = C.c_void_p(0)
+        return check(lib.doa_root_pipeline_work(self._h, n, ptr_array([a.ctypes.data for a in arrs]),
+                                                none if cov_out is None else _vp(cov_out), _vp(angles_out)))
+
+
 class compass_mean(_Block):
     """blocks.vector_to_streams(float, num_streams) + the averaging step of doa.compass
     (reference python/compass.py:134-136: next_angle = numpy.mean(input_items[0]) per work call),

@@ -23,11 +23,21 @@
  *                                lib/rootMUSIC_linear_array_impl.cc:46-152
  *   doa_music_pipeline_*         the three blocks as wired by apps/run_MUSIC_lin_array_simulation.grc
  *                                (autocorrelate -> MUSIC_lin_array -> find_local_max(M, P, 0, 180))
+ *   doa_root_pipeline_*          the two blocks as wired by apps/run_RootMUSIC_lin_array_simulation.grc
+ *                                (autocorrelate -> rootMUSIC_linear_array)
  *
  * Threading: like GNU Radio's thread-per-block scheduler assumes, different handles may be used
  * from different threads concurrently; one handle must not be used from two threads at once.
  * Ownership: the caller owns every buffer it passes; the library owns its device tables, staging
  * buffers and (for the host-pointer entry points) one HIP stream per handle.
+ * What the library does to the HOST PROCESS besides that: the first handle created on a device makes it create four
+ * throw-away non-blocking HIP streams and run one 64-byte memset on each; they (and 64 bytes of device memory) stay alive for
+ * the life of the process.  The HIP runtime maps streams onto its hardware queues lazily, and streams that caused a queue to be
+ * created overlap kernels measurably worse than later ones (26 against 33 us per pipeline step); priming
+ * the pool once makes every stream created afterwards -- the library's and the application's -- one of the good kind.
+ * Set DOA_HIP_NO_QUEUE_PRIMING=1 in the environment to switch this off.
+ * Diagnostics, profiling and fault-injection entry points used by the test suite are exported by the same library but
+ * declared in doa_hip_test.h, not here: this header is the drop-in boundary only.
  */
 #ifndef DOA_HIP_H
 #define DOA_HIP_H
@@ -140,19 +150,13 @@ DOA_HIP_API int doa_MUSIC_lin_array_work(doa_MUSIC_lin_array_t *h, int noutput_i
 DOA_HIP_API int doa_MUSIC_lin_array_work_dev(doa_MUSIC_lin_array_t *h, int noutput_items,
                                              const void *d_input_items0, void *d_output_items0,
                                              void *hip_stream);
-/* Diagnostics used by the parity tests (host buffers, synchronous): the noise-subspace projector
- * U_N U_N^H of each item (column-major num_ant_ele^2 gr_complex, lib/MUSIC_lin_array_impl.cc:133)
- * and the un-normalised null spectrum Q_i = Re(a_i^H P_N a_i) (:139), pspectrum_len floats per
- * item.  Either output pointer may be NULL. */
-DOA_HIP_API int doa_MUSIC_lin_array_debug(doa_MUSIC_lin_array_t *h, int noutput_items,
-                                          const void *input_items0, void *projector_out,
-                                          void *null_spectrum_out);
 /* Diagnostics for tests: for 4 < num_ant_ele <= 16 and num_targets <= 4 (2 num_targets <= num_ant_ele), internal
  * precision 64, the noise projector of MUSIC / Root-MUSIC / music_pipeline handles is computed from the SIGNAL subspace
  * (shifted orthogonal iteration, every result checked by its residual and by a certificate that the subspace found is the
  * one of the num_targets largest eigenvalues), and an item that fails any check takes the full Jacobi
  * eigendecomposition instead.  This returns how many items took that fall-back since the last reset (process-wide, all
- * handles; synchronises the device), or -1 without a device. */
+ * handles and all devices: one 64-bit device counter per device, each kernel adds into the counter of the device it runs on;
+ * synchronises the devices), or -1 without a device. */
 DOA_HIP_API long long doa_hip_evd_fallback_count(int reset);
 /* Items processed so far — the counter the reference prints from its destructor
  * (lib/MUSIC_lin_array_impl.cc:92-95,146). */
@@ -192,25 +196,6 @@ DOA_HIP_API doa_rootMUSIC_linear_array_t *doa_rootMUSIC_linear_array_create(floa
 DOA_HIP_API void doa_rootMUSIC_linear_array_destroy(doa_rootMUSIC_linear_array_t *h);
 DOA_HIP_API int doa_rootMUSIC_linear_array_work(doa_rootMUSIC_linear_array_t *h, int noutput_items,
                                                 const void *input_items0, void *output_items0);
-/* Diagnostics for parity tests (as doa_MUSIC_lin_array_debug): besides the angles, the 2*num_ant_ele-2 polynomial
- * roots the solver found per item (roots_out: interleaved re, im doubles; may be NULL) and the per-item status
- * (status_out: 1 = no root strictly inside the unit circle, the case in which the reference raises inside
- * arma::index_min and doa_..._work returns DOA_ERR_NUMERIC; may be NULL).  Always returns noutput_items on success. */
-DOA_HIP_API int doa_rootMUSIC_linear_array_debug(doa_rootMUSIC_linear_array_t *h, int noutput_items,
-                                                 const void *input_items0, void *output_items0,
-                                                 void *roots_out, int *status_out);
-/* Diagnostics, second half: ONLY the root-selection stage of work() (lib/rootMUSIC_linear_array_impl.cc:122-145), run
- * on the device -- the very code the solver kernel ends in -- on CALLER-SUPPLIED roots (roots_in: noutput_items x
- * (2*num_ant_ele-2) interleaved re, im doubles, host memory), so that every branch of the rule can be driven with
- * hand-made root lists: fewer than num_targets roots strictly inside the unit circle (missing slots read 90 degrees,
- * :131-141), roots exactly on the circle (excluded by dist > 0, :125), equal distances (index_min takes the first),
- * no interior root at all (status 1 / NaN angles; the reference raises).  PARITY UNPINNED in two corners, both stated
- * in DESIGN.md section 5: the reference tests a FLOAT dist = 1 - |z| of cgeev's float roots, here dist is formed in double from
- * double roots (a root within 6e-8 of the circle is dropped there and kept here); NaN angles (|arg z| > 2 pi d) sort
- * last here, arma::sort's treatment of NaN depends on the Armadillo version. */
-DOA_HIP_API int doa_rootMUSIC_linear_array_select_debug(doa_rootMUSIC_linear_array_t *h, int noutput_items,
-                                                        const void *roots_in, void *output_items0,
-                                                        int *status_out);
 DOA_HIP_API int doa_rootMUSIC_linear_array_work_dev(doa_rootMUSIC_linear_array_t *h,
                                                     int noutput_items, const void *d_input_items0,
                                                     void *d_output_items0, void *hip_stream);
@@ -275,7 +260,7 @@ DOA_HIP_API int doa_calibrate_lin_array_set_internal_precision(doa_calibrate_lin
  *   the ANGLES-ONLY mode: for the benchmark-shaped spectra (pspectrum_len 256 / 512 / 1024, polynomial size = array size)
  *   the scan kernel then neither converts the row to dB nor writes it (the maximum of a normalised row is 0 dB by
  *   construction and its position follows from the null spectrum itself); peaks and angles are bit-identical to a call
- *   that asks for the spectrum (23.9 against 25.7 us per 4096-snapshot step on MI355X).
+ *   that asks for the spectrum (21.1 against 25.3 us per 4096-snapshot step on MI355X, 500-step runs of round 3).
  * --------------------------------------------------------------------------------------------- */
 typedef struct doa_music_pipeline doa_music_pipeline_t;
 
@@ -325,10 +310,6 @@ DOA_HIP_API int doa_music_pipeline_set_lanes(doa_music_pipeline_t *h, int n_lane
  * another) -- the program that owns the process's streams is the one that can choose. */
 DOA_HIP_API int doa_music_pipeline_set_lane_streams(doa_music_pipeline_t *h, int n_lanes, void *const *hip_streams);
 DOA_HIP_API int doa_music_pipeline_set_internal_precision(doa_music_pipeline_t *h, int bits);
-/* Profiling aid: which stages later work_dev calls on this handle launch (bit 0 = K1 covariance, bit 1 = K2+K3
- * EVD, bit 2 = K4+K5 scan + peak pick; default 7).  A dropped stage leaves its outputs as the previous call
- * wrote them, so a profiler can time one kernel on valid intermediates; not for production use. */
-DOA_HIP_API int doa_music_pipeline_set_stages(doa_music_pipeline_t *h, int stage_mask);
 /* The same three blocks on HOST buffers (the layouts the GNU Radio scheduler hands to the blocks'
  * work(): input_items[k] = stream k, doa_autocorrelate_input_span(noutput_items) samples; outputs
  * noutput_items items each).  cov_out and spectrum_out may be NULL: only the 2*num_targets floats
@@ -339,15 +320,47 @@ DOA_HIP_API int doa_music_pipeline_set_stages(doa_music_pipeline_t *h, int stage
 DOA_HIP_API int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items,
                                         const void *const *input_items, void *cov_out,
                                         void *spectrum_out, void *max_out, void *argmax_out);
-/* Test aids for the error paths of doa_music_pipeline_work and doa_music_pipeline_work_dev_batches (not for production
- * use).  inject_failure: the NEXT such call on this handle behaves as if a HIP call had failed in chunk `chunk_index` (0 =
- * the first ~32 MiB chunk, or the only one of a scheduler-sized call) after that chunk's uploads were enqueued -- for the
- * batches entry: before batch `chunk_index` is launched, the earlier ones already running on their lanes; one-shot, -1
- * disarms.  Whatever fails inside either call, it returns only after every lane it used has been synchronised (the
- * detached form included), so nothing of a failed call is still running or copying afterwards; lanes_idle reports exactly
- * that (1 = all lanes idle, 0 = work pending, < 0 = error). */
-DOA_HIP_API int doa_music_pipeline_inject_failure(doa_music_pipeline_t *h, int chunk_index);
-DOA_HIP_API int doa_music_pipeline_lanes_idle(doa_music_pipeline_t *h);
+
+/* ---------------------------------------------------------------------------------------------
+ * root_pipeline — autocorrelate -> rootMUSIC_linear_array on device-resident streams: the Root-MUSIC branch of the hot
+ *   path as one handle (the chain apps/run_RootMUSIC_lin_array_simulation.grc wires; reference work being chained:
+ *   lib/autocorrelate_impl.cc:83-118 -> lib/rootMUSIC_linear_array_impl.cc:90-152).  Same conventions as music_pipeline:
+ *   all pointers are DEVICE pointers except the pointer arrays themselves; d_cov_out may be NULL.  Output: num_targets
+ *   floats per snapshot, angles in degrees, ascending (rootMUSIC_linear_array's output 0).
+ *   d_status_out (optional): one int per snapshot, 1 = the polynomial has no root strictly inside the unit circle -- the
+ *   case in which the reference raises inside arma::index_min and the host entry returns DOA_ERR_NUMERIC; the device entries
+ *   are asynchronous and leave the check to the caller.  Results are bit-identical to the two block handles chained by hand
+ *   (doa_autocorrelate_work_dev -> doa_rootMUSIC_linear_array_work_dev).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct doa_root_pipeline doa_root_pipeline_t;
+
+DOA_HIP_API doa_root_pipeline_t *doa_root_pipeline_create(int inputs, int snapshot_size, int overlap_size,
+                                                          int avg_method, float norm_spacing, int num_targets,
+                                                          int max_batch);
+DOA_HIP_API void doa_root_pipeline_destroy(doa_root_pipeline_t *h);
+/* Same fusion as doa_autocorrelate_fuse_antenna_correction, for the pipeline's K1. */
+DOA_HIP_API int doa_root_pipeline_fuse_antenna_correction(doa_root_pipeline_t *h, const float *gains_re_im);
+DOA_HIP_API int doa_root_pipeline_work_dev(doa_root_pipeline_t *h, int noutput_items,
+                                           const void *const *d_input_items, void *d_cov_out,
+                                           void *d_angles_out, int *d_status_out, void *hip_stream);
+/* n_batches independent batches in ONE call, overlapped over the handle's lanes; arguments, stream semantics
+ * (DOA_STREAM_DETACHED included), error contract and return value as doa_music_pipeline_work_dev_batches.
+ *   d_cov_out, d_status_out   HOST arrays of n_batches DEVICE pointers; the array or single entries may be NULL
+ *   d_angles_out              HOST array of n_batches DEVICE pointers (required) */
+DOA_HIP_API int doa_root_pipeline_work_dev_batches(doa_root_pipeline_t *h, int n_batches, int noutput_items,
+                                                   const void *const *d_input_items, void *const *d_cov_out,
+                                                   void *const *d_angles_out, int *const *d_status_out,
+                                                   void *hip_stream);
+DOA_HIP_API int doa_root_pipeline_synchronize(doa_root_pipeline_t *h);
+DOA_HIP_API int doa_root_pipeline_set_lanes(doa_root_pipeline_t *h, int n_lanes);
+DOA_HIP_API int doa_root_pipeline_set_lane_streams(doa_root_pipeline_t *h, int n_lanes, void *const *hip_streams);
+DOA_HIP_API int doa_root_pipeline_set_internal_precision(doa_root_pipeline_t *h, int bits);
+/* The same chain on HOST buffers (the layouts the GNU Radio scheduler hands to the blocks' work()); cov_out may be NULL.
+ * Scheduler-sized calls take one staged copy each way, large ones ~32 MiB chunks alternating over two streams; returns when
+ * every output has landed: noutput_items, or DOA_ERR_NUMERIC if some item had no root inside the unit circle (the angles of
+ * the other items are valid, that item's are NaN). */
+DOA_HIP_API int doa_root_pipeline_work(doa_root_pipeline_t *h, int noutput_items,
+                                       const void *const *input_items, void *cov_out, void *angles_out);
 
 /* ---------------------------------------------------------------------------------------------
  * compass_mean — blocks.vector_to_streams(float, num_streams) + the averaging of doa.compass

@@ -9,12 +9,26 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "doa_hip.h")
+TEST_HEADER = os.path.join(ROOT, "include", "doa_hip_test.h")       # diagnostics / profiling / fault injection: not the boundary
+
+
+def _declared_in(path):
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"DOA_HIP_API\s+[\w\s\*]+?\b(doa_\w+)\s*\(", src)))
 
 
 def _declared():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"DOA_HIP_API\s+[\w\s\*]+?\b(doa_\w+)\s*\(", src)))
+    return sorted(set(_declared_in(HEADER)) | set(_declared_in(TEST_HEADER)))
+
+
+def test_the_boundary_header_carries_no_test_hooks():
+    """doa_hip.h is what a gr-doa block shell binds; fault injection, stage masks and *_debug entries live in doa_hip_test.h."""
+    boundary = _declared_in(HEADER)
+    assert not [n for n in boundary if n.endswith("_debug") or "inject" in n or n.endswith("_lanes_idle") or n.endswith("_set_stages")]
+    hooks = _declared_in(TEST_HEADER)
+    assert "doa_music_pipeline_inject_failure" in hooks and "doa_root_pipeline_inject_failure" in hooks
+    assert not set(boundary) & set(hooks)
 
 
 def test_header_declares_the_expected_entry_points():
@@ -23,6 +37,8 @@ def test_header_declares_the_expected_entry_points():
         for suffix in ("create", "work", "work_dev", "destroy"):
             assert f"doa_{blk}_{suffix}" in names
     assert "doa_music_pipeline_work_dev" in names and "doa_last_error" in names
+    for suffix in ("create", "work", "work_dev", "work_dev_batches", "synchronize", "set_lanes", "destroy"):
+        assert f"doa_root_pipeline_{suffix}" in names
 
 
 def test_library_exports_every_declared_symbol():
@@ -38,7 +54,7 @@ def test_library_is_not_older_than_its_sources():
     lib = os.path.join(ROOT, "gr-doa_amd", "lib", "libdoa_hip.so")
     src_dir = os.path.join(ROOT, "gr-doa_amd", "csrc")
     newest = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir))
-    newest = max(newest, os.path.getmtime(HEADER))
+    newest = max(newest, os.path.getmtime(HEADER), os.path.getmtime(TEST_HEADER))
     assert os.path.getmtime(lib) >= newest, "libdoa_hip.so is stale: run make -C gr-doa_amd"
 
 

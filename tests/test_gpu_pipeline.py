@@ -418,6 +418,39 @@ def test_large_batch_scan_equals_small_batches():
     assert bool(same.all())
 
 
+@pytest.mark.parametrize("N,P,M,angles_only", [(4, 1024, 2, False), (3, 512, 2, False), (2, 256, 1, False), (4, 512, 3, False),
+                                                (4, 256, 1, True), (4, 1024, 1, True), (4, 1024, 2, True)])
+def test_large_batch_cooperative_scan_variants(N, P, M, angles_only):
+    """From 16384 items on, the lean scan kernels run in their workgroup-cooperative form (one 16-wave workgroup per CU, rows of
+    a workgroup 32 KiB apart, one barrier per item: music_scan_impl.hpp, COOP).  Every variant of it -- all three lean spectrum
+    lengths, num_max_vals > 1 (an LDS row per wave), the angles-only form -- must give the bits of the same items processed 4096 at
+    a time by the plain form, with a ragged tail (the last turn of most workgroups is partly barrier-only) and irregular rows."""
+    K, d = 16, 0.5
+    n = 16 * 4096 + 4096 + 531
+    s, _ = doa.sim.make_batch_streams_torch(N, K, n, d, M, 15.0, seed=92, device="cuda")
+    s[0][K * 40001 + 5] = float("nan")
+    s[N - 1][K * (n - 3) + 1] = float("inf")
+    st = torch.cuda.current_stream()
+    big = doa.music_pipeline(N, K, 0, 0, d, M, P, n)
+    M_out = M
+    spec = torch.full((n, P), -7.0, dtype=torch.float32, device="cuda")
+    mx = torch.empty((n, M_out), dtype=torch.float32, device="cuda")
+    am = torch.empty((n, M_out), dtype=torch.float32, device="cuda")
+    big.work_dev(n, [t.data_ptr() for t in s], 0, 0 if angles_only else spec.data_ptr(), mx.data_ptr(), am.data_ptr(), st)
+    small = doa.music_pipeline(N, K, 0, 0, d, M_out, P, 4096)
+    spec2 = torch.empty((4096, P), dtype=torch.float32, device="cuda")
+    mx2 = torch.empty((4096, M_out), dtype=torch.float32, device="cuda")
+    am2 = torch.empty((4096, M_out), dtype=torch.float32, device="cuda")
+    for i0 in (0, 36000, n - 4096):
+        small.work_dev(4096, [t[i0 * K:].data_ptr() for t in s], 0, spec2.data_ptr(), mx2.data_ptr(), am2.data_ptr(), st)
+        torch.cuda.synchronize()
+        if not angles_only:
+            a, b = spec[i0:i0 + 4096], spec2
+            assert bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all()), i0
+        assert torch.equal(torch.nan_to_num(am[i0:i0 + 4096], nan=-1.0), torch.nan_to_num(am2, nan=-1.0)), i0
+        assert torch.equal(torch.nan_to_num(mx[i0:i0 + 4096], nan=-1.0), torch.nan_to_num(mx2, nan=-1.0)), i0
+
+
 @pytest.mark.parametrize("detached", [True, False])
 def test_batches_entry_failure_leaves_nothing_running(detached):
     """An error return of doa_music_pipeline_work_dev_batches means nothing of the call is still running -- in the detached

@@ -6,7 +6,7 @@ sys.path[:0] = [os.path.join(ROOT, "gr-doa_amd", "python")]
 import numpy as np
 import torch
 import doa
-N, K, B, P, M = 4, 64, 20000, 1024, 1
+N, K, B, P, M = 4, 64, int(os.environ.get("SCAN_CHECK_BATCH", "20000")), 1024, 1
 st = torch.cuda.current_stream()
 pipe = doa.music_pipeline(N, K, 0, 0, 0.5, M, P, B)
 s, _ = doa.sim.make_batch_streams_torch(N, K, B, 0.5, M, 20.0, seed=5, device="cuda")
