@@ -362,7 +362,7 @@ def other_configs(doa, torch, st, lanes=4, check=True):
     """Driver-timed figures for the other BASELINE.json configs (parity-test cases, never the headline): configs[2] (Root-MUSIC,
     N=4, 2 sources), configs[3] (N=16, 3 sources, P=4096, MFMA covariance) and the simulation flowgraph's shape (K=2048,
     overlap 512, forward-backward, 2 sources).  Each: us per 4096-snapshot step serial (one stream) and overlapped (the
-    handle's lanes; for Root-MUSIC, which has no fused entry, caller streams), items/s; preceded -- outside any timing -- by a
+    handle's lanes: doa_music_pipeline / doa_root_pipeline work_dev_batches), items/s; preceded -- outside any timing -- by a
     16-row spot check against the oracle (the checker leg of this script, like cpu_baseline: fp64 restatement of the
     reference's formulas on the same samples)."""
     import numpy as np
@@ -442,7 +442,8 @@ def other_configs(doa, torch, st, lanes=4, check=True):
                      "items_per_s_serial": B / us_serial * 1e6, "items_per_s_overlapped": (B / us_lanes * 1e6) if us_lanes else None,
                      "overlap": f"doa_music_pipeline_work_dev_batches (detached), {lanes} lanes", "spot_check": chk}
 
-    # configs[2]: covariance + Root-MUSIC (no fused entry: two blocks on one stream; overlapped = 4 caller streams)
+    # configs[2]: covariance + Root-MUSIC through ONE handle (doa_root_pipeline, round 4): serial = one work_dev per step on one
+    # stream, overlapped = all steps as one doa_root_pipeline_work_dev_batches call over the handle's lanes (detached form)
     try:
         N, K, d, M = 4, 1024, 0.44, 2
         nbuf = 4
@@ -450,28 +451,29 @@ def other_configs(doa, torch, st, lanes=4, check=True):
         ptrs = [[t.data_ptr() for t in s] for s in bufs]
         cov = [torch.empty((B, N * N), dtype=torch.complex64, device="cuda") for _ in range(nbuf)]
         ang = [torch.empty((B, M), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
-        covb = [doa.autocorrelate(N, K, 0, 0) for _ in range(lanes)]
-        rootb = [doa.rootMUSIC_linear_array(d, M, N) for _ in range(lanes)]
-        sts = [torch.cuda.Stream() for _ in range(lanes)]
+        rp = doa.root_pipeline(N, K, 0, 0, d, M, B)
+        rp.set_lanes(lanes)
         def serial(n):
             for i in range(n):
                 b = i % nbuf
-                covb[0].work_dev(B, ptrs[b], cov[b].data_ptr(), st)
-                rootb[0].work_dev(B, cov[b].data_ptr(), ang[b].data_ptr(), st)
+                rp.work_dev(B, ptrs[b], cov[b].data_ptr(), ang[b].data_ptr(), None, st)
+        rcalls = {}
         def overl(n):
-            for i in range(n):
-                b, k = i % nbuf, i % lanes
-                covb[k].work_dev(B, ptrs[b], cov[b].data_ptr(), sts[k])
-                rootb[k].work_dev(B, cov[b].data_ptr(), ang[b].data_ptr(), sts[k])
+            if n not in rcalls:                       # pointer arrays marshalled once, as a C caller has them
+                idx = [i % nbuf for i in range(n)]
+                rcalls[n] = rp.prepare_batches(B, [ptrs[b] for b in idx], [cov[b].data_ptr() for b in idx], [ang[b].data_ptr() for b in idx],
+                                               None, doa.DETACHED)
+            rcalls[n]()                               # (timed() joins with a device synchronise, as for the MUSIC handle)
         serial(1)
         torch.cuda.synchronize()
         chk = spot("cfg3", bufs[0], N, K, 0, 0, d, M, 0, cov[0], None, ang[0])
         us_s, us_o = timed(serial, 20), timed(overl, 20)
         out["cfg3_root_music"] = {"config": "BASELINE.json configs[2]: N=4, 2 sources, d=0.44, K=1024, covariance + Root-MUSIC", "batch": B,
                                   "us_per_step_serial": us_s, "us_per_step_overlapped": us_o, "items_per_s_serial": B / us_s * 1e6,
-                                  "items_per_s_overlapped": B / us_o * 1e6, "overlap": f"{lanes} caller streams, one handle pair each (two Python calls per step: host-bound above ~20 us/step)",
+                                  "items_per_s_overlapped": B / us_o * 1e6,
+                                  "overlap": f"doa_root_pipeline_work_dev_batches (detached), {lanes} lanes, one call for all steps",
                                   "spot_check": chk}
-        del bufs, cov, ang
+        del bufs, cov, ang, rp
     except Exception as e:
         out["cfg3_root_music"] = {"error": repr(e)}
     for args_ in (("flowgraph_shape", 4, 2048, 512, 1, 0.4, 2, 1024, 4, 20,

@@ -12,6 +12,7 @@
 #include "jacobi.hpp"
 #include "kernels.hpp"
 #include <mutex>
+#include <type_traits>
 
 #include <cstdlib>
 
@@ -20,6 +21,16 @@ namespace doa {
 }  // namespace doa
 #include "evd_subspace.hpp"
 namespace doa {
+
+// Q(psi) = u0 + 2 sum_l (x_l cos(l psi) - y_l sin(l psi)), u_l = x_l + j y_l, in powers of c = cos psi and s = sin psi
+// (cos 2x = 2c^2 - 1, cos 3x = 4c^3 - 3c, sin 2x = 2sc, sin 3x = s(4c^2 - 1)):  Q = A(c) + s B(c),
+// A = (u0 - 2x2) + (2x1 - 6x3) c + 4x2 c^2 + 8x3 c^3,  B = (2y3 - 2y1) - 4y2 c - 8y3 c^2   (music_scan_impl.hpp: ChebQ)
+// ux[l], uy[l]: u_l for l = 0..3 (zero beyond the array size)
+__device__ __forceinline__ void write_cheb_record(double *__restrict__ o, const double (&ux)[4], const double (&uy)[4])
+{
+    o[0] = ux[0] - 2 * ux[2]; o[1] = 2 * ux[1] - 6 * ux[3]; o[2] = 4 * ux[2]; o[3] = 8 * ux[3];
+    o[4] = 2 * uy[3] - 2 * uy[1]; o[5] = -4 * uy[2]; o[6] = -8 * uy[3]; o[7] = 0.0;
+}
 
 template <int N, typename T>
 __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
@@ -56,16 +67,9 @@ __global__ __launch_bounds__(64) void music_evd_kernel(const float2 *__restrict_
         for (int k = 0; k < 2 * N; k++) coef_d[(size_t)item * (2 * N) + k] = (double)u[k];
     }
     if (cheb_d) {
-        // Q(psi) = u0 + 2 sum_l (x_l cos(l psi) - y_l sin(l psi)), u_l = x_l + j y_l, in powers of c = cos psi and s = sin psi
-        // (cos 2x = 2c^2 - 1, cos 3x = 4c^3 - 3c, sin 2x = 2sc, sin 3x = s(4c^2 - 1)):  Q = A(c) + s B(c),
-        // A = (u0 - 2x2) + (2x1 - 6x3) c + 4x2 c^2 + 8x3 c^3,  B = (2y3 - 2y1) - 4y2 c - 8y3 c^2   (music_scan_impl.hpp: ChebQ)
-        const double u0 = (double)u[0];
-        const double x1 = (N > 1) ? (double)u[1] : 0.0, y1 = (N > 1) ? (double)u[2] : 0.0;
-        const double x2 = (N > 2) ? (double)u[3] : 0.0, y2 = (N > 2) ? (double)u[4] : 0.0;
-        const double x3 = (N > 3) ? (double)u[5] : 0.0, y3 = (N > 3) ? (double)u[6] : 0.0;
-        double *o = cheb_d + (size_t)item * kChebRecord;
-        o[0] = u0 - 2 * x2; o[1] = 2 * x1 - 6 * x3; o[2] = 4 * x2; o[3] = 8 * x3;
-        o[4] = 2 * y3 - 2 * y1; o[5] = -4 * y2; o[6] = -8 * y3; o[7] = 0.0;
+        const double ux[4] = {(double)u[0], (N > 1) ? (double)u[1] : 0.0, (N > 2) ? (double)u[3] : 0.0, (N > 3) ? (double)u[5] : 0.0};
+        const double uy[4] = {0.0, (N > 1) ? (double)u[2] : 0.0, (N > 2) ? (double)u[4] : 0.0, (N > 3) ? (double)u[6] : 0.0};
+        write_cheb_record(cheb_d + (size_t)item * kChebRecord, ux, uy);
     }
 }
 
@@ -204,7 +208,8 @@ template <int G, typename T>
 __device__ __forceinline__ void evd_group_epilogue(T (&vr)[G], T (&vi)[G], T lam, bool real_col, int r, int base, int lane,
                                                    int item, bool real_item, int N, int M, float *__restrict__ coef,
                                                    double *__restrict__ coef_d, float2 *__restrict__ pn_out,
-                                                   const float2 *__restrict__ pilot, float2 *__restrict__ cal_out)
+                                                   const float2 *__restrict__ pilot, float2 *__restrict__ cal_out,
+                                                   double *__restrict__ cheb_d = nullptr)
 {
     // eigenvalue of lane r = A[r][r]; ascending rank inside the group; noise set = ranks < N-M
     int rank = 0;
@@ -266,8 +271,9 @@ __device__ __forceinline__ void evd_group_epilogue(T (&vr)[G], T (&vi)[G], T lam
     // u_l = sum_r P_N[r+l][r] = sum_r sum_i Y[r+l][i] conj(V[r][i]): fetch row r+l, dot with own row, reduce
     float *co = (coef && real_item) ? coef + (size_t)item * (2 * N) : nullptr;
     double *cd = (coef_d && real_item) ? coef_d + (size_t)item * (2 * N) : nullptr;
-    for (int l = 0; l < N; l++) {
-        T tr = 0, ti = 0;
+    double ux[4] = {0, 0, 0, 0}, uy[4] = {0, 0, 0, 0};       // u_l = ux + j uy for the lean scan's record (G == 4 only)
+    auto diagonal_sum = [&](int l, T &tr, T &ti) {
+        tr = 0; ti = 0;
         const int src = (r + l < G) ? base + r + l : lane;
 #pragma unroll
         for (int i = 0; i < G; i++) {
@@ -287,12 +293,37 @@ __device__ __forceinline__ void evd_group_epilogue(T (&vr)[G], T (&vi)[G], T lam
                 if (cd) { cd[2 * l - 1] = (double)tr; cd[2 * l] = (double)ti; }
             }
         }
+    };
+    if constexpr (G == 4) {                                  // unrolled: the record copy keeps static indices
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            if (l < N) {
+                T tr, ti;
+                diagonal_sum(l, tr, ti);
+                ux[l] = (double)tr; uy[l] = (l == 0) ? 0.0 : (double)ti;
+            }
+        }
+    } else {
+        for (int l = 0; l < N; l++) {
+            T tr, ti;
+            diagonal_sum(l, tr, ti);
+        }
     }
     if (r == 0) {
         if (co) co[2 * N - 1] = 0.f;
         if (cd) cd[2 * N - 1] = 0.0;
+        if constexpr (G == 4) {
+            if (cheb_d && real_item) write_cheb_record(cheb_d + (size_t)item * kChebRecord, ux, uy);
+        }
     }
 }
+
+// the whole group Jacobi of one wave: G lanes per item, `real_item` = this lane's group stores its results
+template <int G, typename T>
+__device__ __forceinline__ void evd_group_wave(const float2 *__restrict__ Ri, int item, bool real_item, int N, int M,
+                                               float *__restrict__ coef, double *__restrict__ coef_d, float2 *__restrict__ pn_out,
+                                               const float2 *__restrict__ pilot, float2 *__restrict__ cal_out,
+                                               double *__restrict__ cheb_d = nullptr);
 
 template <int G, typename T>
 __global__ __launch_bounds__(64) void music_evd_group_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
@@ -302,11 +333,20 @@ __global__ __launch_bounds__(64) void music_evd_group_kernel(const float2 *__res
 {
     constexpr int IPW = kWave / G;                       // items per wave
     const int lane = threadIdx.x & (kWave - 1);
-    const int r = lane % G, base = lane - r;
     int item = blockIdx.x * IPW + lane / G;
     const bool real_item = item < n_items;
     if (!real_item) item = n_items - 1;                  // idle groups shadow the last item (no stores)
-    const float2 *Ri = R + (size_t)item * (N * N);
+    evd_group_wave<G, T>(R + (size_t)item * (N * N), item, real_item, N, M, coef, coef_d, pn_out, pilot, cal_out);
+}
+
+template <int G, typename T>
+__device__ __forceinline__ void evd_group_wave(const float2 *__restrict__ Ri, int item, bool real_item, int N, int M,
+                                               float *__restrict__ coef, double *__restrict__ coef_d, float2 *__restrict__ pn_out,
+                                               const float2 *__restrict__ pilot, float2 *__restrict__ cal_out,
+                                               double *__restrict__ cheb_d)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r = lane % G, base = lane - r;
 
     T ar[G], ai[G], vr[G], vi[G];
 #pragma unroll
@@ -363,7 +403,324 @@ __global__ __launch_bounds__(64) void music_evd_group_kernel(const float2 *__res
     // plausible-looking record built from an identity V
 #pragma unroll
     for (int k = 0; k < G; k++) vr[k] += poison;
-    evd_group_epilogue<G, T>(vr, vi, lam, r < N, r, base, lane, item, real_item, N, M, coef, coef_d, pn_out, pilot, cal_out);
+    evd_group_epilogue<G, T>(vr, vi, lam, r < N, r, base, lane, item, real_item, N, M, coef, coef_d, pn_out, pilot, cal_out, cheb_d);
+}
+
+// ---------------------------------------------------------------------------------------------
+// N <= 4 with two or three sources (round 4): the signal-subspace iteration of evd_subspace.hpp with FOUR LANES PER ITEM --
+// a DPP quad, 16 items per wave.  The one-lane form (evd_small_subspace) loses at M >= 2: a wave runs as long as the slowest of
+// its 64 items and every lane carries the whole 4 x 4 . 4 x M product as one dependent chain (11.9 against the Jacobi's 10.8 us
+// per 4096 items at M = 2, 30 against 10.4 on forward-backward data).  Here lane r of a quad holds ROW r: of A, skewed
+// (As[s] = A[r][(r + s) mod 4], so that y = A x is three quad rotations of x against registers with compile-time indices), and
+// of every column of X and Y; the Gram / Ritz sums are two-step quad reductions, the M x M Cholesky and the triangular
+// solve run redundantly in the four lanes, nothing touches LDS.  Same checks, same constants as the other two forms
+// (residual 3e-14 ||A||, top-M certificate, Cholesky breakdown, non-finite or zero input, 20 steps) and the same
+// consequence: a quad that fails any of them takes the cyclic Jacobi -- evd_group_wave<4> in the same wave, which keeps
+// the reference's behaviour for ties (ranks by index).  Rows r >= N are zero padding (they stay zero through the iteration).
+// ---------------------------------------------------------------------------------------------
+template <int S> __device__ __forceinline__ double quad_rot(double v)      // lane r takes the value of quad lane (r + S) mod 4
+{
+    return quad_fetch<quad_pattern(S & 3, (1 + S) & 3, (2 + S) & 3, (3 + S) & 3)>(v);
+}
+__device__ __forceinline__ double quad_sum(double v)
+{
+    v += quad_fetch<quad_pattern(1, 0, 3, 2)>(v);
+    v += quad_fetch<quad_pattern(2, 3, 0, 1)>(v);
+    return v;                                                  // the same bits in the four lanes (a + b == b + a)
+}
+
+// ok (quad-uniform): X holds an orthonormal basis of the top-MC eigenspace, certified
+template <int MC>
+__device__ __forceinline__ bool evd_quad_subspace(const float2 *__restrict__ Ri, int N, int r, double (&xcr)[MC], double (&xci)[MC])
+{
+    static_assert(MC >= 1 && MC <= 3, "columns");
+    auto elem = [&](int row, int col) -> float2 {              // A[row][col] from the upper triangle (cheevd uplo = 'U')
+        if (row >= N || col >= N) return make_float2(0.f, 0.f);
+        if (row == col) return make_float2(Ri[row + col * N].x, 0.f);
+        const float2 x = (row < col) ? Ri[row + col * N] : Ri[col + row * N];
+        return make_float2(x.x, (row < col) ? x.y : -x.y);
+    };
+    double ar[4], ai[4];
+    float m = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const float2 e = elem(r, (r + s) & 3);
+        ar[s] = (double)e.x; ai[s] = (double)e.y;
+        m = fmaxf(m, fmaxf(fabsf(e.x), fabsf(e.y)));
+    }
+    m = fmaxf(m, quad_fetch<quad_pattern(1, 0, 3, 2)>(m));
+    m = fmaxf(m, quad_fetch<quad_pattern(2, 3, 0, 1)>(m));
+    bool ok = (m > 0.f) && (m < INFINITY);                     // zero, NaN (fmaxf drops it: the poison below) or inf -> Jacobi
+    const double sc = jacobi_prescale<double>(ok ? m : 1.f);
+    double nrm2 = 0.0, poison = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        poison = fma(ar[s], 0.0, fma(ai[s], 0.0, poison));     // NaN if any entry is non-finite
+        ar[s] *= sc; ai[s] *= sc;
+        nrm2 = fma(ar[s], ar[s], fma(ai[s], ai[s], nrm2));
+    }
+    nrm2 = quad_sum(nrm2);                                     // ||A||_F^2
+    poison = quad_sum(poison);
+    ok = ok && (poison == 0.0);
+    const double trA = quad_sum(ar[0]);
+
+    double ycr[MC], yci[MC];
+    // Cholesky-QR of the columns in (ycr, yci) -> (xcr, xci); false on breakdown (quad-uniform)
+    auto cholqr = [&]() -> bool {
+        double gr[MC][MC], gi[MC][MC];                         // Gram matrix, upper triangle
+#pragma unroll
+        for (int i = 0; i < MC; i++)
+#pragma unroll
+            for (int j = i; j < MC; j++) {
+                gr[i][j] = quad_sum(fma(ycr[i], ycr[j], yci[i] * yci[j]));              // conj(y_i) y_j
+                gi[i][j] = (j > i) ? quad_sum(fma(ycr[i], yci[j], -yci[i] * ycr[j])) : 0.0;
+            }
+        double lr[MC][MC], li[MC][MC], inv[MC];
+        bool good = true;
+#pragma unroll
+        for (int j = 0; j < MC; j++) {
+            double d = gr[j][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) d -= fma(lr[j][k], lr[j][k], li[j][k] * li[j][k]);
+            good = good && (d > 1e-280) && (d < 1e280);
+            const double dd = good ? d : 1.0;
+            inv[j] = Real<double>::rsqrt(dd);
+            lr[j][j] = dd * inv[j]; li[j][j] = 0.0;
+#pragma unroll
+            for (int i = j + 1; i < MC; i++) {
+                // L[i][j] = (G[i][j] - sum_k L[i][k] conj(L[j][k])) / L[j][j],  G[i][j] = conj(G[j][i])
+                double tr = gr[j][i], ti = -gi[j][i];
+#pragma unroll
+                for (int k = 0; k < j; k++) {
+                    tr -= fma(lr[i][k], lr[j][k], li[i][k] * li[j][k]);
+                    ti -= fma(li[i][k], lr[j][k], -lr[i][k] * li[j][k]);
+                }
+                lr[i][j] = tr * inv[j]; li[i][j] = ti * inv[j];
+            }
+        }
+        // Y = Q R, R = L^H: q_j = (y_j - sum_{i<j} q_i conj(L[j][i])) / L[j][j]   (harmless numbers when !good)
+#pragma unroll
+        for (int j = 0; j < MC; j++) {
+            double tr = ycr[j], ti = yci[j];
+#pragma unroll
+            for (int i = 0; i < j; i++) {
+                tr -= fma(xcr[i], lr[j][i], xci[i] * li[j][i]);
+                ti -= fma(xci[i], lr[j][i], -xcr[i] * li[j][i]);
+            }
+            xcr[j] = tr * inv[j]; xci[j] = ti * inv[j];
+        }
+        return good;
+    };
+    // start: the first MC columns of A
+#pragma unroll
+    for (int c = 0; c < MC; c++) {
+        const float2 e = elem(r, c);
+        ycr[c] = (double)e.x * sc; yci[c] = (double)e.y * sc;
+    }
+    ok = cholqr() && ok;
+    double mu = 0.0;
+    const double inv_nm = 1.0 / (double)(N - MC);
+    bool done = false;                                         // done / ok are quad-uniform; the wave leaves the loop on a ballot
+    int next_check = 4;
+    for (int it = 1; it <= 20; it++) {
+        // y_c = A x_c - mu x_c for every column, at this lane's row
+        double tsum = 0.0;
+#pragma unroll
+        for (int c = 0; c < MC; c++) {
+            double yr = fma(ar[0], xcr[c], fma(-ai[0], xci[c], -mu * xcr[c]));
+            double yi = fma(ar[0], xci[c], fma(ai[0], xcr[c], -mu * xci[c]));
+            {
+                const double pr = quad_rot<1>(xcr[c]), pi = quad_rot<1>(xci[c]);
+                yr = fma(ar[1], pr, fma(-ai[1], pi, yr)); yi = fma(ar[1], pi, fma(ai[1], pr, yi));
+            }
+            {
+                const double pr = quad_rot<2>(xcr[c]), pi = quad_rot<2>(xci[c]);
+                yr = fma(ar[2], pr, fma(-ai[2], pi, yr)); yi = fma(ar[2], pi, fma(ai[2], pr, yi));
+            }
+            {
+                const double pr = quad_rot<3>(xcr[c]), pi = quad_rot<3>(xci[c]);
+                yr = fma(ar[3], pr, fma(-ai[3], pi, yr)); yi = fma(ar[3], pi, fma(ai[3], pr, yi));
+            }
+            // a finished (or failed) quad keeps its X: its Y is not used again
+            ycr[c] = yr; yci[c] = yi;
+            tsum = fma(xcr[c], yr, fma(xci[c], yi, tsum));
+        }
+        if (it == next_check) {
+            // T' = X^H Y = X^H A X - mu I (upper triangle, mirrored), residual ||Y - X T'||_F
+            double tr_[MC][MC], ti_[MC][MC];
+#pragma unroll
+            for (int i = 0; i < MC; i++)
+#pragma unroll
+                for (int j = i; j < MC; j++) {
+                    const double pr = quad_sum(fma(xcr[i], ycr[j], xci[i] * yci[j]));
+                    const double pi = (j > i) ? quad_sum(fma(xcr[i], yci[j], -xci[i] * ycr[j])) : 0.0;
+                    tr_[i][j] = pr; ti_[i][j] = pi;
+                    tr_[j][i] = pr; ti_[j][i] = -pi;
+                }
+            double res2 = 0.0, t2 = 0.0, trT = 0.0;
+#pragma unroll
+            for (int j = 0; j < MC; j++) {
+                double rr = ycr[j], ri = yci[j];
+#pragma unroll
+                for (int i = 0; i < MC; i++) {
+                    rr -= fma(xcr[i], tr_[i][j], -xci[i] * ti_[i][j]);
+                    ri -= fma(xcr[i], ti_[i][j], xci[i] * tr_[i][j]);
+                    t2 = fma(tr_[i][j], tr_[i][j], fma(ti_[i][j], ti_[i][j], t2));
+                }
+                res2 = fma(rr, rr, fma(ri, ri, res2));
+                trT += tr_[j][j];
+            }
+            res2 = quad_sum(res2);
+            const bool conv = res2 <= (3e-14 * 3e-14) * nrm2;
+            {
+                // certificate (evd_subspace.hpp, header): Cholesky of T' for its determinant, AM-GM bound on theta_min - mu.
+                // Evaluated at every check, converged or not: the same two numbers -- sqrt(E) >= every outside |lambda_j - mu|,
+                // `bound` <= theta_min - mu -- also bound the iteration's RATE from above, and an item whose rate says "ten more
+                // steps" is handed to the Jacobi now instead of after 20 steps (a wave pays for its slowest quad)
+                double lr[MC][MC], li[MC][MC], det = 1.0;
+                bool pd = true;
+#pragma unroll
+                for (int j = 0; j < MC; j++) {
+                    double d = tr_[j][j];
+#pragma unroll
+                    for (int k = 0; k < j; k++) d -= fma(lr[j][k], lr[j][k], li[j][k] * li[j][k]);
+                    pd = pd && (d > 0.0);
+                    const double dd = pd ? d : 1.0;
+                    det *= dd;
+                    const double iv = Real<double>::rsqrt(dd);
+                    lr[j][j] = dd * iv; li[j][j] = 0.0;
+#pragma unroll
+                    for (int i = j + 1; i < MC; i++) {
+                        double a_ = tr_[i][j], b_ = ti_[i][j];
+#pragma unroll
+                        for (int k = 0; k < j; k++) {
+                            a_ -= fma(lr[i][k], lr[j][k], li[i][k] * li[j][k]);
+                            b_ -= fma(li[i][k], lr[j][k], -lr[i][k] * li[j][k]);
+                        }
+                        lr[i][j] = a_ * iv; li[i][j] = b_ * iv;
+                    }
+                }
+                double bound = det;
+                if constexpr (MC > 1) {
+                    const double f = (double)(MC - 1) / trT;
+#pragma unroll
+                    for (int k = 0; k < MC - 1; k++) bound *= f;
+                }
+                const double En = fma((double)N * mu, mu, fma(-2.0 * mu, trA, nrm2)) - t2;
+                const bool sane = pd && (trT > 0.0) && (bound > 0.0);
+                const bool cert = sane && (bound * bound > 1.02 * fmax(En, 0.0) + 1e-12 * nrm2);
+                if (ok && !done) {
+                    if (conv) {
+                        if (cert) done = true;                  // X stays as it is from here on
+                        else ok = false;                        // converged to SOME invariant subspace: the Jacobi decides
+                    } else if (!sane || En > 0.04 * bound * bound) {
+                        ok = false;                             // rate above 0.2 per step (or no bound at all): not worth iterating
+                    }
+                }
+            }
+            next_check += (it < 8) ? 2 : (it == 8 ? 3 : (it == 11 ? 4 : 5));      // checks after 4, 6, 8, 11, 15, 20 steps
+        }
+        if (__builtin_amdgcn_ballot_w64(ok && !done) == 0ull) break;
+        // shift = mean of the eigenvalues outside span X, from the traces; next X (only for quads still iterating)
+        tsum = quad_sum(tsum);                                 // tr(X^H A X) - MC mu
+        const double mu_next = (trA - tsum - (double)MC * mu) * inv_nm;
+        double kr[MC], ki[MC];
+#pragma unroll
+        for (int c = 0; c < MC; c++) { kr[c] = xcr[c]; ki[c] = xci[c]; }
+        const bool good = cholqr();
+        const bool live = ok && !done;
+        if (live) { mu = mu_next; ok = good; }
+        else {
+#pragma unroll
+            for (int c = 0; c < MC; c++) { xcr[c] = kr[c]; xci[c] = ki[c]; }
+        }
+    }
+    return ok && done;
+}
+
+// one DPP quad per item, 16 items per wave; MC = num_targets (2 or 3; N = MC + 1 .. 4)
+template <int MC, bool PN>
+__global__ __launch_bounds__(64) void music_evd_quad_kernel(const float2 *__restrict__ R, float *__restrict__ coef,
+                                                            double *__restrict__ coef_d, float2 *__restrict__ pn_out, int n_items,
+                                                            int N, double *__restrict__ cheb_d,
+                                                            unsigned long long *__restrict__ fallback_count)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r = lane & 3;
+    int item = blockIdx.x * 16 + (lane >> 2);
+    const bool real_item = item < n_items;
+    if (!real_item) item = n_items - 1;                        // idle quads shadow the last item (no stores)
+    const float2 *Ri = R + (size_t)item * (N * N);
+    double xcr[MC], xci[MC];
+    const bool fast = evd_quad_subspace<MC>(Ri, N, r, xcr, xci);
+    if (fast && real_item) {
+        // u_l = N delta_l0 - sum_r sum_c X[r+l][c] conj(X[r][c]), r + l < N: row r + l is l lanes further on in the quad
+        double ux[4] = {0, 0, 0, 0}, uy[4] = {0, 0, 0, 0};
+        auto diag = [&](auto l_tag) {
+            constexpr int l = decltype(l_tag)::value;
+            double tr = 0.0, ti = 0.0;
+#pragma unroll
+            for (int c = 0; c < MC; c++) {
+                const double ur = quad_rot<l>(xcr[c]), ui = quad_rot<l>(xci[c]);
+                tr = fma(ur, xcr[c], fma(ui, xci[c], tr));
+                ti = fma(ui, xcr[c], fma(-ur, xci[c], ti));
+            }
+            if (!(r + l < N)) { tr = 0.0; ti = 0.0; }
+            ux[l] = ((l == 0) ? (double)N : 0.0) - quad_sum(tr);
+            uy[l] = (l == 0) ? 0.0 : -quad_sum(ti);
+        };
+        diag(std::integral_constant<int, 0>{});
+        diag(std::integral_constant<int, 1>{});
+        diag(std::integral_constant<int, 2>{});
+        diag(std::integral_constant<int, 3>{});
+        if (r == 0) {
+            float *co = coef ? coef + (size_t)item * (2 * N) : nullptr;
+            double *cd = coef_d ? coef_d + (size_t)item * (2 * N) : nullptr;
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                if (l < N) {
+                    if (l == 0) {
+                        if (co) co[0] = (float)ux[0];
+                        if (cd) cd[0] = ux[0];
+                    } else {
+                        if (co) { co[2 * l - 1] = (float)ux[l]; co[2 * l] = (float)uy[l]; }
+                        if (cd) { cd[2 * l - 1] = ux[l]; cd[2 * l] = uy[l]; }
+                    }
+                }
+            }
+            if (co) co[2 * N - 1] = 0.f;
+            if (cd) cd[2 * N - 1] = 0.0;
+            if (cheb_d) write_cheb_record(cheb_d + (size_t)item * kChebRecord, ux, uy);
+        }
+        if constexpr (PN) {
+            if (pn_out) {
+                // P_N[a][b] = delta_ab - sum_c X[a][c] conj(X[b][c]); this lane: a = r, b = (r + s) mod 4
+                float2 *po = pn_out + (size_t)item * (N * N);
+                auto col = [&](auto s_tag) {
+                    constexpr int s = decltype(s_tag)::value;
+                    const int b = (r + s) & 3;
+                    double pr = (s == 0) ? 1.0 : 0.0, pi = 0.0;
+#pragma unroll
+                    for (int c = 0; c < MC; c++) {
+                        const double wr = quad_rot<s>(xcr[c]), wi = quad_rot<s>(xci[c]);      // X[b][c]
+                        pr -= fma(xcr[c], wr, xci[c] * wi);
+                        pi -= fma(xci[c], wr, -xcr[c] * wi);
+                    }
+                    if (r < N && b < N) po[r + b * N] = make_float2((float)pr, (float)pi);
+                };
+                col(std::integral_constant<int, 0>{});
+                col(std::integral_constant<int, 1>{});
+                col(std::integral_constant<int, 2>{});
+                col(std::integral_constant<int, 3>{});
+            }
+        }
+    }
+    // quads the iteration did not certify: the cyclic Jacobi, in this wave (skipped when there is none)
+    const bool need = real_item && !fast;
+    if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+        if (fallback_count && need && r == 0) atomicAdd(fallback_count, 1ull);
+        evd_group_wave<4, double>(Ri, item, need, N, MC, coef, coef_d, PN ? pn_out : nullptr, nullptr, nullptr, cheb_d);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -749,6 +1106,22 @@ int launch_calibrate(int N, int n_items, const void *d_R, const void *d_pilot, v
     return DOA_OK;
 }
 
+// N <= 4, two or three sources, double: four lanes per item (music_evd_quad_kernel)
+static bool launch_evd_quad(int N, int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn, hipStream_t st,
+                            void *d_cheb)
+{
+    // two sources only: with three (N = 4: ONE noise eigenvalue) 1.6 % of random-direction items fall back and take their
+    // waves with them -- 26 against the Jacobi's 11 us per 4096 items (profiles/r04_lab_evd_quad.txt)
+    if (N > 4 || M != 2 || M >= N) return false;
+    const dim3 grid((n_items + 15) / 16), block(64);
+#define DOA_QUAD(M_, PN_)                                                                                                    \
+    hipLaunchKernelGGL((music_evd_quad_kernel<M_, PN_>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,              \
+                       (double *)d_coef_d, (float2 *)d_pn, n_items, N, (double *)d_cheb, evd_fallback_counter())
+    if (d_pn) DOA_QUAD(2, true); else DOA_QUAD(2, false);
+#undef DOA_QUAD
+    return true;
+}
+
 template <int N> static void launch_evd_n(int M, int n_items, const void *d_R, void *d_coef, void *d_coef_d, void *d_pn,
                                           int bits, hipStream_t st, void *d_cheb)
 {
@@ -785,6 +1158,8 @@ int launch_music_evd(int N, int M, int n_items, const void *d_R, void *d_coef, v
     } else if (N > 4) {
         if (f32) launch_evd_group<8, float>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
         else launch_evd_group<8, double>(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st);
+    } else if (!f32 && DOA_LAB_ENV_INT("DOA_EVD_QUAD", 1) && launch_evd_quad(N, M, n_items, d_R, d_coef, d_coef_d, d_pn, st, d_cheb)) {
+        // (N <= 4 with M >= 2 in double; M = 1 keeps the one-lane iteration below)
     } else {
         switch (N) {
         case 2: launch_evd_n<2>(M, n_items, d_R, d_coef, d_coef_d, d_pn, evd_bits, st, d_cheb); break;

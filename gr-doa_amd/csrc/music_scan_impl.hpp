@@ -364,37 +364,18 @@ __device__ __forceinline__ void lean_scan_item_irregular(const LeanQ<N, T> &Q, c
 // irregular path use `row` as scratch.
 // ABL (lab builds only, make LAB=1): 1 = everything but the row stores, 2 = the row stores only (results invalid) -- the
 // two ablations behind the "what bounds this kernel" numbers in DESIGN.md
-// HOLD (row pairs, large batches; !MULTI, STORE): 1 = the dB row is not stored but left in `held` (a row that took the irregular
-// path is written at once and leaves held_row = nullptr); 2 = every chunk of this row is stored right behind the same chunk of
-// the row held from the previous call (held_row), so that the two rows -- 32 KiB apart, i.e. quarters of the same DRAM pages --
-// reach the memory system together.  See music_scan_peak1_kernel.
-struct HeldRow {
-    float *row = nullptr;        // where the held row goes (nullptr: nothing held)
-};
-template <int N, int CH, typename T, bool MULTI, bool PEAKS = true, bool STORE = true, int ABL = 0, bool PAIRED = false>
+template <int N, int CH, typename T, bool MULTI, bool PEAKS = true, bool STORE = true, int ABL = 0>
 __device__ __forceinline__ void lean_scan_item(const T (&c)[LeanRecord<N, T>::kLen], const T (&zr)[CH][4], const T (&zi)[CH][4],
                                                const T *__restrict__ ztab, float *__restrict__ row,
                                                const float *__restrict__ xs, float *__restrict__ pk_val_item,
-                                               float *__restrict__ pk_loc_item, int M, int lane, float *lds_row,
-                                               float (&held)[CH][4], HeldRow &hr, int hold)
+                                               float *__restrict__ pk_loc_item, int M, int lane, float *lds_row = nullptr)
 {
-    // hold (wave-uniform; PAIRED kernels only): 0 store the row, 1 keep it in `held`, 2 store it behind the held row, chunk by
-    // chunk.  A run-time value on purpose: one copy of this function per kernel (three inlined copies took the kernel from
-    // 104 to 192 VGPRs)
-    static_assert(!PAIRED || (!MULTI && STORE), "row pairs exist for the single-peak kernels that write their spectrum");
     constexpr int P = 256 * CH;
     const LeanQ<N, T> Q(c);
     if constexpr (ABL == 2) {
-        if (PAIRED && hold == 1) hr.row = row;
-        else {
 #pragma unroll
-            for (int j = 0; j < CH; j++) {
-                if constexpr (PAIRED)
-                    if (hr.row) store_f4<true>(reinterpret_cast<float4 *>(hr.row + 4 * lane + 256 * j), make_float4((float)lane, (float)j, -1.f, -2.f));
-                store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4((float)lane, (float)j, -1.f, -2.f));
-            }
-            hr.row = nullptr;
-        }
+        for (int j = 0; j < CH; j++)
+            store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4((float)lane, (float)j, -1.f, -2.f));
         if (lane == 0) { pk_val_item[0] = 0.0f; pk_loc_item[0] = xs[lane]; }
         return;                 // (nothing here depends on the item's record)
     }
@@ -475,44 +456,8 @@ __device__ __forceinline__ void lean_scan_item(const T (&c)[LeanRecord<N, T>::kL
                     }
                 }
                 if constexpr (STORE && ABL == 1) keep += (db[0] + db[1]) + (db[2] + db[3]);
-                else if constexpr (STORE && PAIRED) {
-                    // paired rows leave this loop in registers, in place of Q; ALL stores of the wave come in one burst behind it
-#pragma unroll
-                    for (int e = 0; e < 4; e++) qf[j][e] = db[e];
-                } else if constexpr (STORE)
+                else if constexpr (STORE)
                     store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j), make_float4(db[0], db[1], db[2], db[3]));
-            }
-            if constexpr (PAIRED && ABL != 1) {
-                // One burst per pair, the same KiB of the two rows back to back (as 2 KiB pieces between the chunks' arithmetic the
-                // pair form was SLOWER than single rows: 240-256 against 217-225 us per 262144 rows, same box).  The empty asm
-                // statements pin the order: left alone, the compiler merges the second row's stores out of the two branches and
-                // the burst goes out row after row, and it turns the copy into `held` into 32 selects per item.
-                if (hold == 1) {                           // (wave-uniform) first row of a pair: keep it
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int j = 0; j < CH; j++)
-#pragma unroll
-                        for (int e = 0; e < 4; e++) held[j][e] = qf[j][e];
-                    hr.row = row;
-                } else if (hr.row) {
-#pragma unroll
-                    for (int j = 0; j < CH; j++) {
-                        store_f4<true>(reinterpret_cast<float4 *>(hr.row + 4 * lane + 256 * j),
-                                       make_float4(held[j][0], held[j][1], held[j][2], held[j][3]));
-                        asm volatile("" ::: "memory");
-                        store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
-                                       make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
-                        asm volatile("" ::: "memory");
-                    }
-                    hr.row = nullptr;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < CH; j++) {
-                        store_f4<true>(reinterpret_cast<float4 *>(row + 4 * lane + 256 * j),
-                                       make_float4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]));
-                        asm volatile("" ::: "memory");
-                    }
-                }
             }
             if constexpr (ABL == 1) { if (keep == 12345.678f) row[lane] = keep; }      // keeps the arithmetic alive; never true
             // (the minimum itself always ties, so pos is a valid angle; the clamp only keeps a broken invariant from
@@ -522,14 +467,6 @@ __device__ __forceinline__ void lean_scan_item(const T (&c)[LeanRecord<N, T>::kL
             }
         }
     } else {
-        if constexpr (PAIRED) {
-            if (hr.row) {
-#pragma unroll
-                for (int j = 0; j < CH; j++)
-                    store_f4<true>(reinterpret_cast<float4 *>(hr.row + 4 * lane + 256 * j), make_float4(held[j][0], held[j][1], held[j][2], held[j][3]));
-            }
-            hr.row = nullptr;
-        }
         lean_scan_item_irregular<N, CH, T, MULTI, PEAKS>(Q, ztab, row, xs, pk_val_item, pk_loc_item, M, lane);
     }
 }
@@ -598,23 +535,11 @@ __device__ __forceinline__ void lean_load_table(const T *__restrict__ ztab, int 
         for (int e = 0; e < 4; e++) asm volatile("" :: "v"(zr[j][e]), "v"(zi[j][e]));
 }
 
-// PAIR (round 4; large batches, single-peak kernels that write their spectrum): what bounds this kernel at large batches is
-// its row stores, and what the write path rewards is DRAM-page locality IN TIME: a 4 KiB row is a
-// quarter of each of the pages it touches, the other quarters belong to the rows 32, 64 and 96 KiB further on, and rows
-// written by independent waves at independent times reach 5.0-5.3 TB/s where a sweep that writes them together reaches the
-// fill rate (6.5).  A wave therefore takes TWO rows `pair_stride` (8: 32 KiB) apart one after the other, keeps the first
-// row's dB values in 16 registers and writes both rows chunk by chunk, the same KiB of the two back to back.
-// tools/lab/scan_proxy.hip (the kernel's two halves, 16 waves per CU): stores alone 199-205 -> 175-179 us per 262144 rows,
-// both halves 208-212 -> 168-184 (hipMemsetAsync of the same bytes: 162-166).  Forms that synchronise MORE rows (16-wave
-// workgroups behind a barrier) write faster still (stores alone 172) but serialise the workgroup's arithmetic with its store
-// burst: measured in this kernel, 240 against 226 us (profiles/r04_lab_scan_coop_real_kernel.txt).
-// Pairs: pair p covers rows a = (p / S) 2S + p % S and a + S (S = pair_stride); the last block of a ragged batch leaves
-// some rows without a partner: they are written alone.
-template <int N, int CH, typename T, bool MULTI = false, bool PEAKS = true, bool STORE = true, int ABL = 0, bool PAIR = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PAIR ? 4 : 1, 8))) void music_scan_peak1_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
+template <int N, int CH, typename T, bool MULTI = false, bool PEAKS = true, bool STORE = true, int ABL = 0>
+__global__ __launch_bounds__(256) void music_scan_peak1_kernel(const T *__restrict__ coef, const T *__restrict__ ztab,
                                                                float *__restrict__ spec, int n_items,
                                                                const float *__restrict__ xaxis, float *__restrict__ pk_val,
-                                                               float *__restrict__ pk_loc, int M, int pair_stride)
+                                                               float *__restrict__ pk_loc, int M)
 {
     constexpr int P = 256 * CH;
     constexpr int RL = LeanRecord<N, T>::kLen;
@@ -636,62 +561,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PAIR ? 4 : 
     // the wait behind pass 1 --; sixteen consecutive items per wave with the records staged through LDS; the last chunk of the
     // table in LDS for five waves per SIMD.  DESIGN.md section 3.)
     T c[RL], c_next[RL];
-    float held[CH][4];                 // (PAIR only; dead otherwise)
-    HeldRow hr;
-    if constexpr (!PAIR) {
-        if (wave < n_items) {
+    if (wave < n_items) {
 #pragma unroll
-            for (int k = 0; k < RL; k++) c_next[k] = coef[(size_t)wave * RL + k];
+        for (int k = 0; k < RL; k++) c_next[k] = coef[(size_t)wave * RL + k];
+    }
+    for (int item = wave; item < n_items; item += n_waves) {
+#pragma unroll
+        for (int i = 0; i < RL; i++) c[i] = c_next[i];
+        const int nxt = item + n_waves;
+        if (nxt < n_items) {
+#pragma unroll
+            for (int i = 0; i < RL; i++) c_next[i] = coef[(size_t)nxt * RL + i];
         }
-        for (int item = wave; item < n_items; item += n_waves) {
-#pragma unroll
-            for (int i = 0; i < RL; i++) c[i] = c_next[i];
-            const int nxt = item + n_waves;
-            if (nxt < n_items) {
-#pragma unroll
-                for (int i = 0; i < RL; i++) c_next[i] = coef[(size_t)nxt * RL + i];
-            }
-            lean_scan_item<N, CH, T, MULTI, PEAKS, STORE, ABL, false>(c, zr, zi, ztab, spec + (size_t)item * P, xs, pk_val + (size_t)item * M,
-                                                                     pk_loc + (size_t)item * M, M, lane, lds_row, held, hr, 0);
-        }
-    } else {
-        // (lab builds: a negative stride = the wave keeps its FIRST record for all its rows -- results invalid; separates the cost of
-        // the record loads under store pressure from everything else)
-        const int S = pair_stride < 0 ? -pair_stride : pair_stride;
-        const bool const_record = pair_stride < 0;
-        const int n_pairs = ((n_items + 2 * S - 1) / (2 * S)) * S;
-        auto first_row = [&](int p) { const int blk = p / S; return blk * 2 * S + (p - blk * S); };
-        auto fetch = [&](int item) {
-#pragma unroll
-            for (int k = 0; k < RL; k++) c_next[k] = coef[(size_t)item * RL + k];
-        };
-        auto take = [&]() {
-#pragma unroll
-            for (int i = 0; i < RL; i++) c[i] = c_next[i];
-        };
-        // the wave's rows in the order it takes them: a(p), a(p) + S, a(p + n_waves), ...; ONE call site of lean_scan_item in a
-        // loop that is not unrolled, the next row's record requested one row ahead
-        int p = wave;
-        int item = (p < n_pairs) ? first_row(p) : n_items;         // (a first row past the end only in the last, ragged block)
-        bool second = false;
-        if (item < n_items) fetch(item);
-#pragma unroll 1
-        while (item < n_items) {
-            take();
-            int nxt, hold;
-            bool nxt_second;
-            if (!second && item + S < n_items) { nxt = item + S; nxt_second = true; hold = 1; }
-            else {
-                p += n_waves;
-                nxt = (p < n_pairs) ? first_row(p) : n_items;
-                nxt_second = false;
-                hold = second ? 2 : 0;
-            }
-            if (nxt < n_items && !const_record) fetch(nxt);
-            lean_scan_item<N, CH, T, MULTI, PEAKS, STORE, ABL, true>(c, zr, zi, ztab, spec + (size_t)item * P, xs, pk_val + (size_t)item * M,
-                                                                    pk_loc + (size_t)item * M, M, lane, lds_row, held, hr, hold);
-            item = nxt; second = nxt_second;
-        }
+        lean_scan_item<N, CH, T, MULTI, PEAKS, STORE, ABL>(c, zr, zi, ztab, spec + (size_t)item * P, xs, pk_val + (size_t)item * M,
+                                                          pk_loc + (size_t)item * M, M, lane, lds_row);
     }
 }
 
@@ -983,23 +866,10 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
             const int waves = (n_items + per_wave - 1) / per_wave;
             lb = (waves + lwpb - 1) / lwpb;
         } else if (lb > cap) lb = cap;
-        // Large batches (every wave of a full grid has >= 4 items), single-peak kernels that write the spectrum: row pairs
-        // (music_scan_peak1_kernel, PAIR); the grid is sized by pairs
-        const int pair_stride = DOA_LAB_ENV_INT("DOA_SCAN_PAIR_STRIDE", 8) * (DOA_LAB_ENV_INT("DOA_SCAN_CONST_RECORD", 0) ? -1 : 1);
-        const bool pair_ok = per_wave16 >= 4 && DOA_LAB_ENV_INT("DOA_SCAN_PAIR", 1);
         dim3 lgrid(lb);
 #define DOA_LEAN_LAUNCH(CH_, MULTI_, PEAKS_, STORE_)                                                               \
-    do {                                                                                                           \
-        if constexpr (!(MULTI_) && (STORE_)) {                                                                     \
-            if (pair_ok) {                                                                                         \
-                hipLaunchKernelGGL((music_scan_peak1_kernel<N, CH_, T, MULTI_, PEAKS_, STORE_, 0, true>), lgrid, lblock, 0, st, rec, \
-                                   z, sp, n_items, pk.xaxis, pk.val, pk.loc, pk.M, pair_stride);                   \
-                break;                                                                                             \
-            }                                                                                                      \
-        }                                                                                                          \
-        hipLaunchKernelGGL((music_scan_peak1_kernel<N, CH_, T, MULTI_, PEAKS_, STORE_>), lgrid, lblock, 0, st, rec, z, sp,  \
-                           n_items, pk.xaxis, pk.val, pk.loc, pk.M, 1);                                            \
-    } while (0)
+    hipLaunchKernelGGL((music_scan_peak1_kernel<N, CH_, T, MULTI_, PEAKS_, STORE_>), lgrid, lblock, 0, st, rec, z, sp,  \
+                       n_items, pk.xaxis, pk.val, pk.loc, pk.M)
 #define DOA_LEAN_CH(MULTI_, PEAKS_, STORE_)                                                                        \
     do {                                                                                                           \
         if (P == 256) DOA_LEAN_LAUNCH(1, MULTI_, PEAKS_, STORE_);                                                  \
@@ -1011,18 +881,12 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
             // ablations of the graded kernel (results invalid): DOA_SCAN_ABLATE=1 no row stores, =2 row stores only
             const int ablate = DOA_LAB_ENV_INT("DOA_SCAN_ABLATE", 0);
             if (ablate && P == 1024 && pk.val && pk.store && pk.M == 1) {
-#define DOA_ABL_LAUNCH(A_)                                                                                         \
-    do {                                                                                                           \
-        if (pair_ok)                                                                                               \
-            hipLaunchKernelGGL((music_scan_peak1_kernel<4, 4, T, false, true, true, A_, true>), lgrid, lblock, 0, st, rec, z, sp, \
-                               n_items, pk.xaxis, pk.val, pk.loc, pk.M, pair_stride);                              \
-        else                                                                                                       \
-            hipLaunchKernelGGL((music_scan_peak1_kernel<4, 4, T, false, true, true, A_>), lgrid, lblock, 0, st, rec, z, sp, \
-                               n_items, pk.xaxis, pk.val, pk.loc, pk.M, 1);                                        \
-    } while (0)
-                if (ablate == 1) DOA_ABL_LAUNCH(1);
-                else DOA_ABL_LAUNCH(2);
-#undef DOA_ABL_LAUNCH
+                if (ablate == 1)
+                    hipLaunchKernelGGL((music_scan_peak1_kernel<4, 4, T, false, true, true, 1>), lgrid, lblock, 0, st, rec, z, sp, n_items,
+                                       pk.xaxis, pk.val, pk.loc, pk.M);
+                else
+                    hipLaunchKernelGGL((music_scan_peak1_kernel<4, 4, T, false, true, true, 2>), lgrid, lblock, 0, st, rec, z, sp, n_items,
+                                       pk.xaxis, pk.val, pk.loc, pk.M);
                 return true;
             }
         }

@@ -12,6 +12,6 @@ no HIP device is usable.  There is no CPU fallback.
 """
 from ._lib import DoaError, LIB_PATH, last_error  # noqa: F401
 from .blocks import (autocorrelate, antenna_correction, phase_correct_hier, read_phase_config, calibrate_lin_array, MUSIC_lin_array, find_local_max, rootMUSIC_linear_array,  # noqa: F401
-                     music_pipeline, root_pipeline, compass_mean, sim_source, set_internal_precision, get_internal_precision, device_count,
+                     music_pipeline, root_pipeline, root_music_pipeline, compass_mean, sim_source, set_internal_precision, get_internal_precision, device_count,
                      evd_fallback_count, DETACHED)
 from . import runtime, sim, sharding, distributed, launch  # noqa: F401

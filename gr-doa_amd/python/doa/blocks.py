@@ -580,6 +580,9 @@ class root_pipeline(_Block):
                                                 none if cov_out is None else _vp(cov_out), _vp(angles_out)))
 
 
+root_music_pipeline = root_pipeline      # the name of the C++ shell (gr::doa::root_music_pipeline) and of grc/doa_root_music_pipeline.xml
+
+
 class compass_mean(_Block):
     """blocks.vector_to_streams(float, num_streams) + the averaging step of doa.compass
     (reference python/compass.py:134-136: next_angle = numpy.mean(input_items[0]) per work call),

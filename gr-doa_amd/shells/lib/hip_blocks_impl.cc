@@ -11,6 +11,8 @@
 //   calibrate_lin_array     gr::sync_block, vlen N^2 complex -> vlen N complex (…/calibrate_lin_array_impl.cc:46-51)
 //   music_pipeline          (not in the reference) the first three wired as in run_MUSIC_lin_array_simulation.grc,
 //                           as one gr::block over doa_music_pipeline_work
+//   root_music_pipeline     (not in the reference) autocorrelate -> rootMUSIC_linear_array wired as in
+//                           run_RootMUSIC_lin_array_simulation.grc, as one gr::block over doa_root_pipeline_work
 // — and turn a failing ABI call into the behaviour a GNU Radio block has for it: constructors throw
 // std::runtime_error / std::invalid_argument (as antenna_correction_impl.cc:58-73 does), work()
 // returns WORK_DONE (-1) after logging, which stops the flowgraph.
@@ -21,6 +23,7 @@
 #include <doa/find_local_max.h>
 #include <doa/music_pipeline.h>
 #include <doa/rootMUSIC_linear_array.h>
+#include <doa/root_music_pipeline.h>
 
 #include <doa_hip.h>
 
@@ -298,6 +301,62 @@ public:
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+class root_music_pipeline_hip : public root_music_pipeline
+{
+    static constexpr int kMaxBatch = 4096;
+    doa_root_pipeline_t *d_h;
+    int d_nonoverlap, d_M;
+
+public:
+    root_music_pipeline_hip(int inputs, int snapshot_size, int overlap_size, int avg_method, float norm_spacing, int num_targets)
+        : gr::block("root_music_pipeline", gr::io_signature::make(inputs, inputs, sizeof(gr_complex)),
+                    gr::io_signature::make(1, 1, num_targets * sizeof(float))),
+          d_h(doa_root_pipeline_create(inputs, snapshot_size, overlap_size, avg_method, norm_spacing, num_targets, kMaxBatch)),
+          d_nonoverlap(snapshot_size - overlap_size), d_M(num_targets)
+    {
+        if (!d_h) throw_create("doa::root_music_pipeline");
+        set_history(overlap_size + 1);                        // as doa::autocorrelate (autocorrelate_impl.cc:56-57)
+        apply_scheduling_hints(this, (size_t)num_targets * sizeof(float));
+    }
+    ~root_music_pipeline_hip() override { doa_root_pipeline_destroy(d_h); }
+
+    void forecast(int noutput_items, gr_vector_int &ninput_items_required) override
+    {
+        for (auto &n : ninput_items_required) n = d_nonoverlap * noutput_items;     // autocorrelate_impl.cc:75-80
+    }
+
+    int work_device_batches(int n_batches, int noutput_items, const void *const *d_input_items, void *const *d_angles_out,
+                            int *const *d_status_out, void *hip_stream) override
+    {
+        const int produced = doa_root_pipeline_work_dev_batches(d_h, n_batches, noutput_items, d_input_items, nullptr, d_angles_out,
+                                                                d_status_out, hip_stream);
+        return produced < 0 ? work_failed("doa::root_music_pipeline", produced) : produced;
+    }
+    int synchronize_device() override { return doa_root_pipeline_synchronize(d_h) == 0 ? 0 : work_failed("doa::root_music_pipeline", -3); }
+    int max_batch() const override { return kMaxBatch; }
+
+    int general_work(int noutput_items, gr_vector_int &, gr_vector_const_void_star &input_items,
+                     gr_vector_void_star &output_items) override
+    {
+        float *aoa = static_cast<float *>(output_items[0]);
+        std::vector<const void *> in(input_items.size());
+        int done = 0;
+        while (done < noutput_items) {                        // the handle's workspace holds kMaxBatch items
+            const int n = noutput_items - done < kMaxBatch ? noutput_items - done : kMaxBatch;
+            for (size_t k = 0; k < in.size(); k++)
+                in[k] = static_cast<const gr_complex *>(input_items[k]) + (size_t)done * d_nonoverlap;
+            // (an item without a root inside the unit circle: DOA_ERR_NUMERIC -- the reference's work() throws there -- stops
+            // the flowgraph like any other failure)
+            const int produced = doa_root_pipeline_work(d_h, n, in.data(), nullptr, aoa + (size_t)done * d_M);
+            if (produced < 0) return work_failed("doa::root_music_pipeline", produced);
+            done += produced;
+        }
+        consume_each(d_nonoverlap * done);                    // autocorrelate_impl.cc:114
+        return done;
+    }
+};
+
 }  // namespace
 
 music_pipeline::sptr music_pipeline::make(int inputs, int snapshot_size, int overlap_size, int avg_method,
@@ -305,6 +364,12 @@ music_pipeline::sptr music_pipeline::make(int inputs, int snapshot_size, int ove
 {
     return gnuradio::get_initial_sptr(new music_pipeline_hip(inputs, snapshot_size, overlap_size, avg_method, norm_spacing,
                                                              num_targets, pspectrum_len));
+}
+root_music_pipeline::sptr root_music_pipeline::make(int inputs, int snapshot_size, int overlap_size, int avg_method,
+                                                    float norm_spacing, int num_targets)
+{
+    return gnuradio::get_initial_sptr(new root_music_pipeline_hip(inputs, snapshot_size, overlap_size, avg_method, norm_spacing,
+                                                                  num_targets));
 }
 calibrate_lin_array::sptr calibrate_lin_array::make(float norm_spacing, int num_ant_ele, float pilot_angle)
 {

@@ -3,6 +3,7 @@
 //     N stream files -> autocorrelate -> MUSIC_lin_array -> find_local_max   (mode "music")
 //     N stream files -> autocorrelate -> rootMUSIC_linear_array               (mode "root")
 //     N stream files -> music_pipeline (the three blocks of "music" as one)   (mode "pipeline")
+//     N stream files -> root_music_pipeline (the two blocks of "root" as one) (mode "root_pipeline")
 // Inputs/outputs are raw little-endian binary files so that the pytest driver (tests/
 // test_gpu_shells.py) can compare every port with the Python binding and the oracle.
 //
@@ -12,12 +13,14 @@
 //   writes <out_prefix>.cov.c64, .spec.f32, .max.f32, .argmax.f32   (music)
 //          <out_prefix>.cov.c64, .aoa.f32                            (root)
 //          <out_prefix>.spec.f32, .max.f32, .argmax.f32              (pipeline)
+//          <out_prefix>.aoa.f32                                      (root_pipeline)
 // and prints the wall time spent inside the blocks' work() calls (host buffers in, host buffers out).
 #include <doa/MUSIC_lin_array.h>
 #include <doa/autocorrelate.h>
 #include <doa/find_local_max.h>
 #include <doa/music_pipeline.h>
 #include <doa/rootMUSIC_linear_array.h>
+#include <doa/root_music_pipeline.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -45,7 +48,7 @@ static void write_file(const std::string &path, const port_data &d)
 int main(int argc, char **argv)
 {
     if (argc != 12) {
-        std::cerr << "usage: run_flowgraph music|root|pipeline in_prefix out_prefix inputs snapshot overlap avg norm_spacing "
+        std::cerr << "usage: run_flowgraph music|root|pipeline|root_pipeline in_prefix out_prefix inputs snapshot overlap avg norm_spacing "
                      "num_targets pspectrum_len max_noutput\n";
         return 2;
     }
@@ -75,6 +78,16 @@ int main(int argc, char **argv)
             out1 = gr::lite::run_block(*pipe1, streams, 1, max_noutput, &w1);
             if (out1[0].bytes != out[0].bytes) throw std::runtime_error("music_pipeline: port 0 differs with ports 1, 2 unconnected");
             std::cout << "angles_only work_seconds " << w1 << " snapshots_per_s " << (w1 > 0 ? out1[0].items() / w1 : 0.0) << std::endl;
+            return 0;
+        }
+        if (mode == "root_pipeline") {
+            auto pipe = gr::doa::root_music_pipeline::make(inputs, snapshot, overlap, avg, d, M);
+            auto out = gr::lite::run_block(*pipe, streams, 1, max_noutput);      // first pass: code load, buffer allocation
+            write_file(out_prefix + ".aoa.f32", out[0]);
+            auto again = gr::lite::run_block(*pipe, streams, 1, max_noutput, &work_s);
+            if (again[0].bytes != out[0].bytes) throw std::runtime_error("root_music_pipeline: second pass differs");
+            std::cout << "items: aoa " << out[0].items() << "\nwork_seconds " << work_s << " snapshots_per_s "
+                      << (work_s > 0 ? out[0].items() / work_s : 0.0) << std::endl;
             return 0;
         }
         auto ac = gr::doa::autocorrelate::make(inputs, snapshot, overlap, avg);

@@ -47,6 +47,12 @@ EXPECT = {
         checks=["$inputs > 0", "$inputs > $num_targets", "$norm_spacing <= 0.5", "$overlap_size < $snapshot_size"],
         sinks=[("complex", None, "$inputs")],
         sources=[("float", "$num_targets", None), ("float", "$num_targets", None), ("float", "$pspectrum_len", None)]),
+    "doa_root_music_pipeline": dict(     # not a reference block: autocorrelate -> rootMUSIC_linear_array as one, same parameter keys
+        make="doa.root_music_pipeline($inputs, $snapshot_size, $overlap_size, $avg_method, $norm_spacing, $num_targets)",
+        params={"inputs": "4", "snapshot_size": "2048", "overlap_size": "512", "avg_method": "0", "norm_spacing": "0.5",
+                "num_targets": "1"},
+        checks=["$inputs > 0", "$inputs > $num_targets", "$norm_spacing <= 0.5", "$overlap_size < $snapshot_size"],
+        sinks=[("complex", None, "$inputs")], sources=[("float", "$num_targets", None)]),
     "doa_rootMUSIC_linear_array": dict(
         make="doa.rootMUSIC_linear_array($norm_spacing, $num_targets, $inputs)",
         params={"norm_spacing": "0.5", "num_targets": "1", "inputs": "1"},

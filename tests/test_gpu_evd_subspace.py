@@ -1,5 +1,5 @@
-"""GPU tests of the signal-subspace path of K2+K3 (csrc/evd_subspace.hpp): for 4 < N <= 16, M <= 4 (one wave per item)
-and for N <= 4, M = 1 (one lane per item) the noise projector is I - X X^H with X from a shifted orthogonal iteration, every item checked by its residual and by a certificate that X
+"""GPU tests of the signal-subspace path of K2+K3 (csrc/evd_subspace.hpp): for 4 < N <= 16, M <= 4 (one wave per item),
+for N <= 4, M = 1 (one lane per item) and -- round 4 -- for N <= 4, M = 2 or 3 (four lanes per item, music_evd_quad_kernel) the noise projector is I - X X^H with X from a shifted orthogonal iteration, every item checked by its residual and by a certificate that X
 spans the M LARGEST eigenvalues; items that fail a check take the full Jacobi EVD on the same wave.
 
 What is pinned here, through the C ABI, against the fp64 oracle (numpy eigh on the same covariance items -- the
@@ -43,7 +43,8 @@ def _array_cov(rng, N, M, snr_db, K):
     return x @ x.conj().T / K
 
 
-@pytest.mark.parametrize("N,M", [(2, 1), (3, 1), (4, 1), (5, 1), (5, 2), (6, 3), (8, 1), (8, 2), (8, 4), (9, 3), (12, 4), (16, 1), (16, 3), (16, 4)])
+@pytest.mark.parametrize("N,M", [(2, 1), (3, 1), (4, 1), (3, 2), (4, 2), (4, 3), (5, 1), (5, 2), (6, 3), (8, 1), (8, 2), (8, 4), (9, 3), (12, 4), (16, 1),
+                                 (16, 3), (16, 4)])
 def test_projector_of_the_fast_path_matches_eigh(N, M):
     rng = np.random.default_rng(100 * N + M)
     mats = [_array_cov(rng, N, M, snr, K) for snr, K in ((20.0, 1024), (10.0, 512), (3.0, 256)) for _ in range(24)]
@@ -56,7 +57,11 @@ def test_projector_of_the_fast_path_matches_eigh(N, M):
     got = pn.reshape(-1, N, N).transpose(0, 2, 1)                 # column-major items
     err = np.abs(got - want).max(axis=(1, 2))
     assert err.max() <= 1e-7, (N, M, err.max())
-    assert n_fb <= len(mats) // 6, (N, M, n_fb)                   # the fast path is the one that ran
+    # the fast path is the one that ran.  Measured fall-back counts on these 72 items (round 4): 0 for every pair except the
+    # ones with 2M = N or three-element arrays -- (12, 4) 5, (8, 4) 3, (3, 2) 2 -- and (6, 3) / (9, 3) / (16, 3) / (16, 4) 1;
+    # (4, 3) has no fast path (one noise eigenvalue: 8 of 72 fell back when it had, and took their waves with them).  Bounds = the measured count + 2 (a regression that sends 15 % of the items down the slow path fails)
+    print("fall-backs", (N, M), n_fb, "of", len(mats))
+    assert n_fb <= {(12, 4): 7, (8, 4): 5, (3, 2): 4}.get((N, M), 2), (N, M, n_fb)
     # production call (coefficient records only, a different kernel instantiation): spectra from both paths agree
     spec = np.empty((len(mats), 256), np.float32)
     assert blk.work(len(mats), [R], [spec]) == len(mats)
@@ -75,7 +80,7 @@ def _check_fallback(R, N, M, expect_all=True, tol=1e-7):
     return pn.reshape(-1, N, N).transpose(0, 2, 1), n_fb
 
 
-@pytest.mark.parametrize("N", [8, 16])
+@pytest.mark.parametrize("N", [4, 8, 16])
 def test_equal_eigenvalues_across_the_boundary_take_the_jacobi_path(N):
     # R = c I and diag(5, 5, 5, 1, ...): with M = 1 or 2 the boundary falls between EQUAL eigenvalues; the certificate
     # cannot hold, the Jacobi kernel's rule (ranks by index among equals) decides, exactly as before this path existed
@@ -104,18 +109,19 @@ def test_start_vectors_orthogonal_to_a_dominant_direction():
     assert np.abs(pn - _pn64(R, N, M)).max() <= 1e-7
 
 
-def test_degenerate_items_take_the_fallback_and_keep_its_semantics():
-    N, M = 8, 2
+@pytest.mark.parametrize("N,M", [(8, 2), (4, 2), (3, 2), (4, 3)])
+def test_degenerate_items_take_the_fallback_and_keep_its_semantics(N, M):
     rng = np.random.default_rng(1)
     good = _array_cov(rng, N, M, 20.0, 256)
     zero = np.zeros((N, N))
-    bad = good.copy(); bad[2, 5] = np.nan
+    bad = good.copy(); bad[1, N - 1] = np.nan
     inf = good.copy(); inf[0, 0] = np.inf
     R = _items([good, zero, bad, inf, good])
     blk = doa.MUSIC_lin_array(0.5, M, N, 64)
     doa.evd_fallback_count(reset=True)
     pn, q = blk.debug(R)
-    assert doa.evd_fallback_count(reset=True) == 3
+    # (N = 4 with three sources has no fast path since round 4's measurements: the Jacobi runs directly and nothing is counted)
+    assert doa.evd_fallback_count(reset=True) == (0 if (N, M) == (4, 3) else 3)
     pn = pn.reshape(-1, N, N).transpose(0, 2, 1)
     assert np.abs(pn[[0, 4]] - _pn64(R[[0, 4]], N, M)).max() <= 1e-7
     assert not np.isfinite(pn[2]).all() and not np.isfinite(pn[3]).all()       # non-finite in, non-finite out (never a plausible record)
@@ -168,3 +174,41 @@ def test_pipeline_and_root_music_through_the_fast_path_full_batch(N, M, P):
     assert root.work(n, [cov.cpu().numpy()], [ang]) == n
     assert np.abs(ang - np.sort(th, axis=1)).max() <= 3.0
     assert np.abs(ang[:k] - oracle.root_music(Rk, 0.5, M, N, "f64")).max() <= 1e-3
+
+
+def test_fallback_counter_lives_on_the_device_that_launches():
+    """the fall-back counter a K2+K3 launch adds into must belong to the device the launch runs on (one
+    counter per device since round 4).  On a one-GPU box: the counter the current device would use is allocated on that
+    device; with two or more: a handle created on device 1 runs an item that must fall back (R = c I) and the count arrives."""
+    import ctypes as C
+    from doa import _lib
+    torch = pytest.importorskip("torch")
+    assert _lib.lib.doa_hip_evd_fallback_counter_device_debug() == torch.cuda.current_device()
+    if doa.device_count() >= 2:
+        with torch.cuda.device(1):
+            assert _lib.lib.doa_hip_evd_fallback_counter_device_debug() == 1
+            blk = doa.MUSIC_lin_array(0.5, 2, 8, 64)
+            doa.evd_fallback_count(reset=True)
+            blk.debug(_items([2.0 * np.eye(8)]))
+            assert doa.evd_fallback_count(reset=True) == 1
+
+
+def test_quad_path_on_forward_backward_flowgraph_items():
+    """The simulation flowgraph's own items (N = 4, two sources, forward-backward averaging: the shape on which the one-lane
+    iteration took 30 us against the Jacobi's 10): projector against eigh, fall-backs counted, and the coefficient records --
+    u_l for Root-MUSIC, the lean scan's (A, B) record through the spectrum -- against the fp64 oracle."""
+    from scenarios import make_input
+    c, x = make_input("grc_music_sim")
+    N, M, P, n = c["N"], c["M"], c["P"], c["n"]
+    R = oracle.autocorrelate(x, c["K"], c["ovl"], c["fb"], n)
+    blk = doa.MUSIC_lin_array(c["d"], M, N, P)
+    doa.evd_fallback_count(reset=True)
+    pn, _ = blk.debug(R)
+    n_fb = doa.evd_fallback_count(reset=True)
+    got = pn.reshape(-1, N, N).transpose(0, 2, 1)
+    assert np.abs(got - _pn64(R, N, M)).max() <= 1e-7
+    assert n_fb <= n // 2
+    spec = np.empty((n, P), np.float32)
+    blk.work(n, [R], [spec])
+    s64 = oracle.music_lin_array(R, c["d"], M, N, P, "f64")
+    assert np.abs(spec - s64).max() <= 2e-3 and np.array_equal(np.argmax(spec, axis=1), np.argmax(s64, axis=1))

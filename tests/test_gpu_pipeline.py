@@ -421,10 +421,11 @@ def test_large_batch_scan_equals_small_batches():
 @pytest.mark.parametrize("N,P,M,angles_only", [(4, 1024, 2, False), (3, 512, 2, False), (2, 256, 1, False), (4, 512, 3, False),
                                                 (4, 256, 1, True), (4, 1024, 1, True), (4, 1024, 2, True)])
 def test_large_batch_cooperative_scan_variants(N, P, M, angles_only):
-    """From 16384 items on, the lean scan kernels run in their workgroup-cooperative form (one 16-wave workgroup per CU, rows of
-    a workgroup 32 KiB apart, one barrier per item: music_scan_impl.hpp, COOP).  Every variant of it -- all three lean spectrum
-    lengths, num_max_vals > 1 (an LDS row per wave), the angles-only form -- must give the bits of the same items processed 4096 at
-    a time by the plain form, with a ragged tail (the last turn of most workgroups is partly barrier-only) and irregular rows."""
+    """From 16384 items on, the lean scan kernels run with 16 waves per CU and every wave loops over many items (the launch
+    shape the row-store studies of rounds 3-4 were made on; the row-pair and workgroup-cooperative forms tried in round 4 were
+    tested with this very test before they were dropped).  Every variant -- all three lean spectrum lengths, num_max_vals > 1
+    (an LDS row per wave), the angles-only form -- must give the bits of the same items processed 4096 at a time, with a ragged
+    tail and irregular rows."""
     K, d = 16, 0.5
     n = 16 * 4096 + 4096 + 531
     s, _ = doa.sim.make_batch_streams_torch(N, K, n, d, M, 15.0, seed=92, device="cuda")

@@ -110,6 +110,22 @@ def test_root_music_flowgraph_through_cpp_shells(tmp_path):
     assert np.all(np.abs(aoa - np.array(c["thetas"], np.float32)[None, :]) <= 2.0)
 
 
+@pytest.mark.parametrize("name,env", [("grc_root_sim", None), ("grc_root_sim", SMALL_CALLS), ("bench_cfg3", SMALL_CALLS), ("five_ant", None)])
+def test_root_pipeline_shell_equals_the_two_chained_shells(tmp_path, name, env):
+    """gr::doa::root_music_pipeline (one block over doa_root_pipeline_work) against autocorrelate -> rootMUSIC_linear_array
+    wired as apps/run_RootMUSIC_lin_array_simulation.grc does: the angle port bit for bit, whatever the call size."""
+    c, x = make_input(name)
+    M = c["M"]
+    S = c["K"] - c["ovl"]
+    x_new = x[:, : (x.shape[1] // S) * S]
+    chain, _ = _run("root", c, x_new, tmp_path, 3, SMALL_CALLS, tag="chain")
+    pipe, log = _run("root_pipeline", c, x_new, tmp_path, 5, env, tag="pipe")
+    a = np.fromfile(f"{chain}.aoa.f32", np.float32).reshape(-1, M)
+    b = np.fromfile(f"{pipe}.aoa.f32", np.float32).reshape(-1, M)
+    assert a.shape[0] == x_new.shape[1] // S and np.array_equal(a, b)
+    assert "snapshots_per_s" in log
+
+
 def test_shell_constructor_rejects_bad_arguments(tmp_path):
     c = dict(N=4, K=16, ovl=16, fb=0, d=0.5, M=1, P=64)           # overlap == snapshot: invalid
     x_new = np.zeros((4, 64), np.complex64)

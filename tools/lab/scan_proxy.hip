@@ -69,8 +69,15 @@ __device__ __forceinline__ void item_body(const Params &p, int item, int lane, c
 #pragma unroll
         for (int k = 0; k < 8; k++) c[k] = (real_t)(1.0 + 0.125 * k + 1e-9 * item);
     } else {
+#ifdef SCALAR_REC
+        const double *__restrict__ rec = (const double *)__builtin_assume_aligned(p.coef, 64);
+        const int uitem = __builtin_amdgcn_readfirstlane(item);
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = (real_t)__builtin_nontemporal_load(rec + (size_t)uitem * 8 + k);
+#else
 #pragma unroll
         for (int k = 0; k < 8; k++) c[k] = (real_t)p.coef[(size_t)item * 8 + k];
+#endif
     }
     float *row = p.spec + (size_t)item * 1024;
     float qf[4][4], cm[4];
