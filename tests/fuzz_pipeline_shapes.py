@@ -12,7 +12,18 @@ import doa
 import doa_oracle as oracle
 
 
-def run(n_cases=60, seed=0, verbose=True):
+# shapes every run starts with (N, M, P, K, overlap, avg_method): one of each scan-kernel family -- lean (256 / 512 / 1024, one
+# peak and several), general register-resident (not a multiple of 256), long-spectrum LDS-row (multiples of 64 up to 4096), the
+# two-pass stream kernel (2048 < P <= 4096 with P % 64 != 0), the generic one (P % 4 != 0) -- with overlap, forward-backward
+# averaging and every eigen-stage path (one-lane, four-lane, wave subspace iteration at G = 8 / 16, Jacobi for 2M > N)
+FORCED = [(4, 1, 1024, 64, 0, 0), (4, 2, 1024, 64, 16, 1), (3, 2, 512, 64, 0, 1), (2, 1, 256, 16, 4, 0), (4, 3, 256, 64, 0, 0),
+          (4, 2, 1000, 64, 0, 0), (5, 2, 768, 64, 16, 1), (8, 2, 2048, 64, 0, 0), (8, 3, 1536, 256, 64, 1), (6, 4, 1024, 64, 0, 0),
+          (16, 3, 4096, 64, 0, 0), (12, 4, 2112, 64, 16, 1), (16, 1, 3008, 16, 0, 0), (9, 3, 2560, 64, 0, 1),
+          (16, 3, 2500, 64, 0, 0), (8, 2, 4000, 64, 16, 1), (4, 2, 3100, 64, 0, 0), (13, 4, 2052, 16, 4, 1),
+          (4, 1, 1023, 64, 0, 0), (7, 2, 2501, 64, 0, 1), (4, 2, 20, 64, 0, 0), (16, 4, 64, 64, 0, 0)]
+
+
+def run(n_cases=60, seed=0, verbose=True, forced=()):
     rng = np.random.default_rng(seed)
     bad = 0
     for case in range(n_cases):
@@ -23,6 +34,8 @@ def run(n_cases=60, seed=0, verbose=True):
         ovl = int(rng.choice([0, 0, K // 4]))
         fb = int(rng.integers(0, 2))
         n = int(rng.integers(1, 40))
+        if case < len(forced):
+            N, M, P, K, ovl, fb = forced[case]
         d = float(rng.choice([0.5, 0.4, 0.44]))
         th = np.sort(rng.uniform(25.0, 155.0, M)) + 4.0 * np.arange(M)
         span = (n - 1) * (K - ovl) + K
@@ -51,6 +64,14 @@ def run(n_cases=60, seed=0, verbose=True):
         a64 = oracle.root_music(cov, d, M, N, "f64")
         both = np.isfinite(a64) & np.isfinite(ang)
         root_ok = np.array_equal(np.isfinite(a64), np.isfinite(ang)) and (not both.any() or np.abs(ang[both] - a64[both]).max() <= 1e-3)
+        # ... and the same chain as one handle (doa.root_pipeline): the block's bits, from the streams
+        rp = doa.root_pipeline(N, K, ovl, fb, d, M, max_batch=n)
+        ang2, cov2 = np.full((n, M), np.nan, np.float32), np.empty((n, N * N), np.complex64)
+        try:
+            rp.work(n, [x[k] for k in range(N)], ang2, cov_out=cov2)
+        except doa.DoaError:
+            pass
+        root_ok = root_ok and np.array_equal(ang2, ang, equal_nan=True) and np.array_equal(cov2.view(np.float32), cov.view(np.float32))
         ok = (root_ok and np.array_equal(mx, o0) and np.array_equal(am, o1) and np.array_equal(v0, q0) and np.array_equal(v1, q1)
               and np.abs(spec - s64).max() <= 2e-4 and np.abs(spec2 - s64).max() <= 2e-4
               and np.all(spec.max(axis=1) == 0.0) and np.all(spec2.max(axis=1) == 0.0))

@@ -245,16 +245,17 @@ def test_root_pipeline_fused_antenna_correction():
     c, x = make_input("bench_cfg3")
     N, M, n = c["N"], c["M"], c["n"]
     g = (np.array([1.0, 0.8, 1.3, 0.9]) * np.exp(1j * np.array([0.0, 0.4, -1.1, 2.0]))).astype(np.complex64)
-    gains = np.stack([g.real, g.imag], axis=1).astype(np.float32).reshape(-1)
     xc = [(x[k] * g[k]).astype(np.complex64) for k in range(N)]
     plain = doa.root_pipeline(N, c["K"], c["ovl"], c["fb"], c["d"], M, max_batch=n)
     a_ref = np.empty((n, M), np.float32)
     plain.work(n, xc, a_ref)
     fused = doa.root_pipeline(N, c["K"], c["ovl"], c["fb"], c["d"], M, max_batch=n)
-    corr = doa.antenna_correction(N, gains=gains) if "gains" in doa.antenna_correction.__init__.__code__.co_varnames else None
-    if corr is None:
-        pytest.skip("antenna_correction has no gains constructor in this binding")
-    fused.fuse_antenna_correction(corr)
+    fused.fuse_antenna_correction(g)                       # (an antenna_correction block or its gains)
     a = np.empty((n, M), np.float32)
     fused.work(n, [x[k] for k in range(N)], a)
     assert np.abs(a - a_ref).max() <= 1e-3
+    fused.fuse_antenna_correction(None)                    # off again: the uncorrected streams' angles
+    b = np.empty((n, M), np.float32)
+    fused.work(n, [x[k] for k in range(N)], b)
+    plain.work(n, [x[k] for k in range(N)], a_ref)
+    assert np.array_equal(b, a_ref)

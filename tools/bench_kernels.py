@@ -31,6 +31,16 @@ for b in range(args.nbuf):
     if os.environ.get("BENCH_NOISE_ONLY"):       # pure noise: the worst case for the iterative kernels
         x = torch.randn((N, B * K, 2), device="cuda", dtype=torch.float32)
         streams.append([torch.view_as_complex(x[n].contiguous()) for n in range(N)])
+    elif OVL > 0:
+        # overlapping windows: ONE continuous stream with fixed directions, the simulation flowgraph's own generator (as bench.py's
+        # flowgraph_shape leg).  Until round 4 this script cut overlapping windows out of per-snapshot random-direction blocks: a
+        # window then straddled two direction sets -- twice the sources the estimator is told about, a covariance without a noise
+        # subspace -- which says nothing about the kernels on array data
+        span = (B - 1) * STEP + K
+        s_ = doa.sim.stream_slab_torch([torch.empty(span, dtype=torch.complex64, device="cuda") for _ in range(N)])
+        th = [30.0, 123.0, 75.0, 150.0][:M]
+        doa.sim_source(N, 0.5, th, [0.03125, 0.0625, 0.11, 0.2][:M], None, None, 0.1, seed=600 + b).work_dev(span, [t.data_ptr() for t in s_], st)
+        streams.append(s_)
     else:                                        # M sources at SNR 20 dB, a random direction set per snapshot
         s_, _ = doa.sim.make_batch_streams_torch(N, K, B, 0.5, M, 20.0, seed=b)     # B*K >= (B-1)*STEP + K samples
         streams.append(s_)
@@ -85,6 +95,11 @@ if "root" in args.stages:
     root_blk = doa.rootMUSIC_linear_array(0.5, M, N)
     ang = [torch.empty((B, M), dtype=torch.float32, device="cuda") for _ in range(nb)]
     res["root_us"] = timeit(lambda i: root_blk.work_dev(B, cov[i % nb].data_ptr(), ang[i % nb].data_ptr(), st))
+if "rootpipe" in args.stages:
+    # configs[2] through ONE handle (doa_root_pipeline): serial steps on one stream
+    rp = doa.root_pipeline(N, K, OVL, FB, 0.5, M, B)
+    ang_rp = [torch.empty((B, M), dtype=torch.float32, device="cuda") for _ in range(nb)]
+    res["rootpipe_us"] = timeit(lambda i: rp.work_dev(B, ptrs[i % nb], cov[i % nb].data_ptr(), ang_rp[i % nb].data_ptr(), None, st))
 skip_later = os.environ.pop("DOA_PIPE_SKIP", None)      # "cov", "evd", "scan" (comma separated): stages to drop AFTER every intermediate holds real data
 def apply_skip(p, on):
     sk = skip_later or ""

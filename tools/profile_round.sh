@@ -2,9 +2,9 @@
 # Collects the rocprofv3 evidence of one round on the GPU box into gpurun_out/prof_<tag>/ (scratch);
 # tools/summarize_profiles.py <tag> then copies the judged summaries into profiles/ (tracked).
 # Every rocprofv3 command has the program itself directly behind `--` (no env/bash hop: switches are exported first), and
-# the PMC passes are separate from the kernel-trace passes.   usage (on the box):  bash tools/profile_round.sh r03
+# the PMC passes are separate from the kernel-trace passes.   usage (on the box):  bash tools/profile_round.sh r04
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -38,7 +38,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     run pmc_${ctr}_scan262144   --pmc $ctr --output-format csv -d $out/pmc_${ctr}_scan262144   -- python3 tools/profile_scan.py --batch 262144 --reps 12
 done
 # the other BASELINE.json configs (parity-test cases, not bench lines)
-run trace_cfg3_root   $T -d $out/trace_cfg3_root   -- python3 tools/bench_kernels.py --M 2 --stages cov,root --reps 40
+run trace_cfg3_root   $T -d $out/trace_cfg3_root   -- python3 tools/bench_kernels.py --M 2 --stages rootpipe --reps 40
 run trace_cfg4_n16    $T -d $out/trace_cfg4_n16    -- python3 tools/bench_kernels.py --N 16 --M 3 --P 4096 --stages pipe --reps 20
 run trace_flowgraph   $T -d $out/trace_flowgraph   -- python3 tools/bench_kernels.py --M 2 --K 2048 --ovl 512 --fb 1 --stages pipe --reps 40
 run trace_n8          $T -d $out/trace_n8          -- python3 tools/bench_kernels.py --N 8 --M 2 --stages pipe --reps 40

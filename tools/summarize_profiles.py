@@ -19,7 +19,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
