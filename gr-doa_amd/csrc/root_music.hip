@@ -108,10 +108,11 @@ __device__ __forceinline__ void root_select(double zr, double zi, bool is_root, 
 
 // DEG = compile-time polynomial degree when it is known to be below GR (N = 4: degree 6 on 8 lanes),
 // so that neither the Horner recurrence nor the root-pair loop spends steps on padding.
-template <int GR, int DEG = GR>
+template <int GR, int DEG = GR, bool FLOAT_PHASE = true>
 __global__ __launch_bounds__(64) void root_music_group_kernel(const double *__restrict__ coef, float *__restrict__ out,
                                                               int *__restrict__ status, int n_items, int N, int M,
-                                                              double two_pi_d, double2 *__restrict__ roots_out)
+                                                              double two_pi_d, double2 *__restrict__ roots_out,
+                                                              int float_iters, float float_tol2)
 {
     constexpr int IPW = kWave / GR;
     const int lane = threadIdx.x & (kWave - 1);
@@ -142,6 +143,72 @@ __global__ __launch_bounds__(64) void root_music_group_kernel(const double *__re
         sincos(ang, &sn, &cs);
         zr = is_root ? rad * cs : 1e6 * (k + 1);          // idle lanes park far away and never move
         zi = is_root ? rad * sn : 0.0;
+    }
+    if constexpr (FLOAT_PHASE) {
+        // Round 4: the first iterations in FLOAT.  This kernel is one dependent chain per wave (512 waves on 1024 SIMDs), so
+        // what an iteration costs is the latency of its instructions, and most of the 10-13 iterations only carry the roots from
+        // the generic starting points into their basins: the same Aberth step on float copies of the coefficients (one
+        // v_rcp_f32 per quotient instead of a seed and two Newton steps in double) until the steps are at float's own floor --
+        // relative 1e-5, or 12 iterations --, then the double iteration below with its residual-based stopping test, unchanged,
+        // which needs two or three more steps from there (cubic convergence).  What comes out has passed exactly the test it
+        // passed before; the roots of a pair z, 1/conj(z), 1e-3..1e-5 apart, are told apart by float well enough to start from.
+        float fzr = (float)zr, fzi = (float)zi;
+        float fcr[DEG + 1], fci[DEG + 1];
+        {
+            // scale by the largest coefficient: float has the range, this keeps p and p' O(1)
+            double mx = 0.0;
+#pragma unroll
+            for (int m = 0; m <= DEG; m++) mx = fmax(mx, ca[m]);
+            const double inv = (mx > 0.0 && mx < 1e300) ? 1.0 / mx : 1.0;
+#pragma unroll
+            for (int m = 0; m <= DEG; m++) { fcr[m] = (float)(cr[m] * inv); fci[m] = (float)(ci[m] * inv); }
+        }
+        for (int it = 0; it < float_iters; it++) {
+            float pr = 0.f, pi = 0.f, dr = 0.f, di = 0.f;
+#pragma unroll
+            for (int m = DEG; m >= 0; m--) {
+                const float ndr = fmaf(dr, fzr, fmaf(-di, fzi, pr));
+                const float ndi = fmaf(dr, fzi, fmaf(di, fzr, pi));
+                dr = ndr; di = ndi;
+                const float npr = fmaf(pr, fzr, fmaf(-pi, fzi, fcr[m]));
+                const float npi = fmaf(pr, fzi, fmaf(pi, fzr, fci[m]));
+                pr = npr; pi = npi;
+            }
+            const float dn = fmaf(dr, dr, di * di);
+            float wr = 1e-3f, wi = 1e-3f;
+            if (dn > 0.f) { const float inv = __builtin_amdgcn_rcpf(dn); wr = (pr * dr + pi * di) * inv; wi = (pi * dr - pr * di) * inv; }
+            float sr = 0.f, si = 0.f;
+#pragma unroll
+            for (int j = 0; j < DEG; j++) {
+                const float ojr = __shfl(fzr, base + j, kWave), oji = __shfl(fzi, base + j, kWave);
+                const float er = fzr - ojr, ei = fzi - oji;
+                const float en = fmaf(er, er, ei * ei);
+                if (j != k && j < D && en > 0.f) { const float inv = __builtin_amdgcn_rcpf(en); sr = fmaf(er, inv, sr); si = fmaf(-ei, inv, si); }
+            }
+            const float qr = 1.f - (wr * sr - wi * si), qi = -(wr * si + wi * sr);
+            const float qn = fmaf(qr, qr, qi * qi);
+            float er = wr, ei = wi;
+            if (qn > 0.f) { const float inv = __builtin_amdgcn_rcpf(qn); er = (wr * qr + wi * qi) * inv; ei = (wi * qr - wr * qi) * inv; }
+            float rel = 0.f;
+            const bool finite_step = (er == er) && (ei == ei) && (fabsf(er) < 1e30f) && (fabsf(ei) < 1e30f);
+            if (is_root && finite_step) {
+                fzr -= er; fzi -= ei;
+                rel = (er * er + ei * ei) / (1.f + fzr * fzr + fzi * fzi);
+            }
+            if (__ballot(rel >= float_tol2) == 0ull) break;  // (squared relative step)
+        }
+        // a float phase that went astray (overflow, NaN) hands back the generic starting point
+        const bool sane = (fzr == fzr) && (fzi == fzi) && (fabsf(fzr) < 1e6f) && (fabsf(fzi) < 1e6f);
+        if (is_root && sane) { zr = (double)fzr; zi = (double)fzi; }
+        // two lanes on the SAME float (the two roots of a pair, unresolved): the repulsion term between them would be
+        // skipped (distance 0) and they would travel together for good; the later one steps aside by 1e-4
+        bool twin = false;
+#pragma unroll
+        for (int j = 0; j < DEG; j++) {
+            const double ojr = __shfl(zr, base + j, kWave), oji = __shfl(zi, base + j, kWave);
+            twin = twin || (j < k && j < D && ojr == zr && oji == zi);
+        }
+        if (is_root && twin) { zr += 1e-4 * (k + 1); zi -= 0.7e-4 * (k + 1); }
     }
     for (int it = 0; it < 80; it++) {
         double pr = 0.0, pi = 0.0, dr = 0.0, di = 0.0, eb = 0.0;
@@ -199,8 +266,18 @@ static void launch_root_group(int N, int M, int n_items, const void *d_coef, voi
 {
     constexpr int IPW = kWave / GR;
     dim3 block(64), grid((n_items + IPW - 1) / IPW);
-    hipLaunchKernelGGL((root_music_group_kernel<GR, DEG>), grid, block, 0, st, (const double *)d_coef, (float *)d_out,
-                       (int *)d_status, n_items, N, M, two_pi_d, (double2 *)d_roots);
+    // float phase: at most kFloatIters iterations, left as soon as every root of the wave moves by less than 1e-3 relative
+    // (profiles/r04_lab_root_float_phase.txt has the sweep behind the two numbers)
+    const int float_iters = DOA_LAB_ENV_INT("DOA_ROOT_FLOAT_ITERS", 12);
+    const float float_tol2 = exp2f(-(float)DOA_LAB_ENV_INT("DOA_ROOT_FLOAT_TOL_LOG2", 33));      // 2^-33 = (1.1e-5)^2
+    if (DOA_LAB_ENV_INT("DOA_ROOT_FLOAT_PHASE", 1))
+        hipLaunchKernelGGL((root_music_group_kernel<GR, DEG, true>), grid, block, 0, st, (const double *)d_coef, (float *)d_out,
+                           (int *)d_status, n_items, N, M, two_pi_d, (double2 *)d_roots, float_iters, float_tol2);
+#ifdef DOA_LAB
+    else
+        hipLaunchKernelGGL((root_music_group_kernel<GR, DEG, false>), grid, block, 0, st, (const double *)d_coef, (float *)d_out,
+                           (int *)d_status, n_items, N, M, two_pi_d, (double2 *)d_roots, 0, 0.f);
+#endif
 }
 
 int launch_root_music(int N, int M, float norm_spacing, int n_items, const void *d_coef, void *d_out, void *d_status,

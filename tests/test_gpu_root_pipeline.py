@@ -245,17 +245,17 @@ def test_root_pipeline_fused_antenna_correction():
     c, x = make_input("bench_cfg3")
     N, M, n = c["N"], c["M"], c["n"]
     g = (np.array([1.0, 0.8, 1.3, 0.9]) * np.exp(1j * np.array([0.0, 0.4, -1.1, 2.0]))).astype(np.complex64)
-    xc = [(x[k] * g[k]).astype(np.complex64) for k in range(N)]
+    xd = [(x[k] / g[k]).astype(np.complex64) for k in range(N)]          # what a mis-calibrated front end delivers
     plain = doa.root_pipeline(N, c["K"], c["ovl"], c["fb"], c["d"], M, max_batch=n)
     a_ref = np.empty((n, M), np.float32)
-    plain.work(n, xc, a_ref)
+    plain.work(n, [x[k] for k in range(N)], a_ref)
     fused = doa.root_pipeline(N, c["K"], c["ovl"], c["fb"], c["d"], M, max_batch=n)
     fused.fuse_antenna_correction(g)                       # (an antenna_correction block or its gains)
     a = np.empty((n, M), np.float32)
-    fused.work(n, [x[k] for k in range(N)], a)
-    assert np.abs(a - a_ref).max() <= 1e-3
-    fused.fuse_antenna_correction(None)                    # off again: the uncorrected streams' angles
-    b = np.empty((n, M), np.float32)
-    fused.work(n, [x[k] for k in range(N)], b)
-    plain.work(n, [x[k] for k in range(N)], a_ref)
-    assert np.array_equal(b, a_ref)
+    fused.work(n, xd, a)
+    assert np.all(np.isfinite(a_ref)) and np.abs(a - a_ref).max() <= 2e-3
+    fused.fuse_antenna_correction(None)                    # off again: the distorted streams' own angles
+    b, b_ref = np.empty((n, M), np.float32), np.empty((n, M), np.float32)
+    fused.work(n, xd, b)
+    plain.work(n, xd, b_ref)
+    assert np.array_equal(b, b_ref, equal_nan=True)
