@@ -680,8 +680,17 @@ __global__ __launch_bounds__(256) void music_scan_peak_long_kernel(const T *__re
                                                                    float *__restrict__ pk_loc, int M)
 {
     constexpr int PMAX = 4096;
-    // 65 KiB per workgroup: two workgroups (8 waves) per CU.  Position p lives at word p + (p >> 6): the passes below touch
+    // 66 624 B of rows + the records below = 66-68 KiB of static LDS per workgroup: two workgroups (8 waves) per CU.  That is more
+    // than the 64 KiB a workgroup gets on the CDNA parts before gfx950 (160 KiB per CU here): this library is written for gfx950
+    // only, and a build for another target must fail here rather than in the linker's resource check.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "music_scan_peak_long_kernel needs more than 64 KiB of LDS per workgroup: gfx950 (MI355X) only"
+#endif
+    // Position p lives at word p + (p >> 6): the passes below touch
     // the row as 64 g + lane, the peak pick as 64 lane + i -- both conflict-free with one pad word per 64
+    // (Round 4: two waves per item sharing one row -- four waves per SIMD instead of two, three workgroup barriers per item --
+    // was built and is NOT faster: 65.0 against 63.2 us per 4096 items at N = 16, P = 4096, 45.7 against 40.7 at N = 8;
+    // tools/lab/scan_long_two_waves_variant.diff.txt, profiles/r04_lab_long_scan_two_waves.txt.  Occupancy is not what holds it.)
     __shared__ float rows[4][PMAX + PMAX / 64 + 4];      // (+4: the peak pick may read position P itself)
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = threadIdx.x / kWave;
@@ -847,7 +856,9 @@ static bool launch_scan_nt(const T *co, const T *z, int P, int n_items, void *d_
     constexpr bool kPre = LeanRecord<N, T>::kPre;
     if (aligned && !q && n_ant == N && (P == 256 || P == 512 || P == 1024) && (!kPre || pk.cheb)) {
         const T *rec = kPre ? static_cast<const T *>(pk.cheb) : co;
-        const int lwpb = DOA_LAB_ENV_INT("DOA_SCAN_WPB", waves_per_block);      // lab: workgroup size in waves
+        // lab: workgroup size in waves, 1..4 (the kernels are bounded to 256 threads and their per-wave LDS rows to four)
+        const int lwpb_env = DOA_LAB_ENV_INT("DOA_SCAN_WPB", waves_per_block);
+        const int lwpb = lwpb_env < 1 ? 1 : (lwpb_env > 4 ? 4 : lwpb_env);
         const dim3 lblock(lwpb * kWave);
         int lb = (n_items + lwpb - 1) / lwpb;
         // Waves per CU: 12 up to a few items per wave (the benchmark batch: 2048 waves with two items each; one item per wave
