@@ -362,7 +362,9 @@ def other_configs(doa, torch, st, lanes=4, check=True):
     """Driver-timed figures for the other BASELINE.json configs (parity-test cases, never the headline): configs[2] (Root-MUSIC,
     N=4, 2 sources), configs[3] (N=16, 3 sources, P=4096, MFMA covariance) and the simulation flowgraph's shape (K=2048,
     overlap 512, forward-backward, 2 sources).  Each: us per 4096-snapshot step serial (one stream) and overlapped (the
-    handle's lanes: doa_music_pipeline / doa_root_pipeline work_dev_batches), items/s; preceded -- outside any timing -- by a
+    handle's lanes: doa_music_pipeline / doa_root_pipeline work_dev_batches) -- as ONE call of 20 (cfg4: 8) batches, the figure
+    comparable with round 3, and as one call of 100 (cfg4: 40), where fill, drain and the host's launch / synchronise latency are
+    amortised as they are in a running stream --, items/s; preceded -- outside any timing -- by a
     16-row spot check against the oracle (the checker leg of this script, like cpu_baseline: fp64 restatement of the
     reference's formulas on the same samples)."""
     import numpy as np
@@ -404,7 +406,7 @@ def other_configs(doa, torch, st, lanes=4, check=True):
         res["ok"] = bool(ok)
         return res
 
-    def pipeline_config(name, N, K, ovl, fb, d, M, P, nbuf, reps, desc):
+    def pipeline_config(name, N, K, ovl, fb, d, M, P, nbuf, reps, steady, desc):
         S = K - ovl
         span = (B - 1) * S + K
         bufs = []
@@ -437,16 +439,20 @@ def other_configs(doa, torch, st, lanes=4, check=True):
         torch.cuda.synchronize()
         chk = spot(name, bufs[0], N, K, ovl, fb, d, M, P, cov[0], am[0], None)
         us_serial = timed(serial, reps)
-        us_lanes = timed(lanes_fn, reps) if nbuf % lanes == 0 or nbuf >= lanes else None
+        ok_lanes = nbuf % lanes == 0 or nbuf >= lanes
+        us_lanes = timed(lanes_fn, reps) if ok_lanes else None
+        us_steady = timed(lanes_fn, steady) if ok_lanes else None       # a longer call: fill, drain and host latency amortised
         out[name] = {"config": desc, "batch": B, "us_per_step_serial": us_serial, "us_per_step_overlapped": us_lanes,
+                     "overlapped_steps_per_call": reps, "us_per_step_overlapped_steady": us_steady, "steady_steps_per_call": steady,
                      "items_per_s_serial": B / us_serial * 1e6, "items_per_s_overlapped": (B / us_lanes * 1e6) if us_lanes else None,
+                     "items_per_s_overlapped_steady": (B / us_steady * 1e6) if us_steady else None,
                      "overlap": f"doa_music_pipeline_work_dev_batches (detached), {lanes} lanes", "spot_check": chk}
 
     # configs[2]: covariance + Root-MUSIC through ONE handle (doa_root_pipeline, round 4): serial = one work_dev per step on one
     # stream, overlapped = all steps as one doa_root_pipeline_work_dev_batches call over the handle's lanes (detached form)
     try:
         N, K, d, M = 4, 1024, 0.44, 2
-        nbuf = 4
+        nbuf = 8                                      # rotating input sets, as the headline's (more than the 256 MiB L3 holds)
         bufs = [doa.sim.make_batch_streams_torch(N, K, B, d, M, SNR_DB, seed=400 + b, device="cuda")[0] for b in range(nbuf)]
         ptrs = [[t.data_ptr() for t in s] for s in bufs]
         cov = [torch.empty((B, N * N), dtype=torch.complex64, device="cuda") for _ in range(nbuf)]
@@ -467,18 +473,19 @@ def other_configs(doa, torch, st, lanes=4, check=True):
         serial(1)
         torch.cuda.synchronize()
         chk = spot("cfg3", bufs[0], N, K, 0, 0, d, M, 0, cov[0], None, ang[0])
-        us_s, us_o = timed(serial, 20), timed(overl, 20)
+        us_s, us_o, us_st = timed(serial, 20), timed(overl, 20), timed(overl, 100)
         out["cfg3_root_music"] = {"config": "BASELINE.json configs[2]: N=4, 2 sources, d=0.44, K=1024, covariance + Root-MUSIC", "batch": B,
-                                  "us_per_step_serial": us_s, "us_per_step_overlapped": us_o, "items_per_s_serial": B / us_s * 1e6,
-                                  "items_per_s_overlapped": B / us_o * 1e6,
+                                  "us_per_step_serial": us_s, "us_per_step_overlapped": us_o, "overlapped_steps_per_call": 20,
+                                  "us_per_step_overlapped_steady": us_st, "steady_steps_per_call": 100, "items_per_s_serial": B / us_s * 1e6,
+                                  "items_per_s_overlapped": B / us_o * 1e6, "items_per_s_overlapped_steady": B / us_st * 1e6,
                                   "overlap": f"doa_root_pipeline_work_dev_batches (detached), {lanes} lanes, one call for all steps",
                                   "spot_check": chk}
         del bufs, cov, ang, rp
     except Exception as e:
         out["cfg3_root_music"] = {"error": repr(e)}
-    for args_ in (("flowgraph_shape", 4, 2048, 512, 1, 0.4, 2, 1024, 4, 20,
+    for args_ in (("flowgraph_shape", 4, 2048, 512, 1, 0.4, 2, 1024, 8, 20, 100,
                    "run_MUSIC_lin_array_simulation.grc's shape: N=4, 2 sources, d=0.4, K=2048, overlap 512, forward-backward, P=1024"),
-                  ("cfg4_n16", 16, 1024, 0, 0, 0.5, 3, 4096, 4, 8,
+                  ("cfg4_n16", 16, 1024, 0, 0, 0.5, 3, 4096, 8, 8, 40,
                    "BASELINE.json configs[3]: N=16, 3 sources, K=1024, P=4096 (MFMA covariance, subspace EVD, LDS-row scan)")):
         try:
             pipeline_config(*args_)
