@@ -418,6 +418,7 @@ def other_configs(doa, torch, st, lanes=4, check=True):
                 s = doa.sim.stream_slab_torch(s)
                 src = doa.sim_source(N, d, [30.0, 123.0][:M], [0.03125, 0.0625][:M], None, None, 0.1, seed=600 + b)
                 src.work_dev(span, [t.data_ptr() for t in s], st)
+                del src                               # (the generator owns a stream; nothing of the set-up stays alive in the timed part)
             bufs.append(s)
         ptrs = [[t.data_ptr() for t in s] for s in bufs]
         cov = [torch.empty((B, N * N), dtype=torch.complex64, device="cuda") for _ in range(nbuf)]

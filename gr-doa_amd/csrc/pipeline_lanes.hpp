@@ -9,6 +9,9 @@
 
 namespace doa {
 
+// n_new streams that were seen to run their kernels beside each other and beside the n_have given ones (lane_streams.hip)
+int create_lane_streams(const hipStream_t *have, int n_have, hipStream_t *out, int n_new);
+
 struct PipeLane {
     hipStream_t st = nullptr;
     bool own_stream = true;         // false: adopted from the caller (doa_*_pipeline_set_lane_streams)
@@ -87,9 +90,19 @@ struct PipeLanes {
         const int L = n_lanes;
         // set-up that cannot leave work behind: failures here return at once
         if (!detached && !fork_ev) DOA_HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        {
+            hipStream_t have[kMaxLanes], fresh[kMaxLanes];
+            int n_have = 0, n_new = 0;
+            for (int l = 0; l < L; l++)
+                if (lanes[l].st) have[n_have++] = lanes[l].st;
+            if (n_have < L) {
+                if (const int rc = create_lane_streams(have, n_have, fresh, L - n_have); rc != DOA_OK) return rc;
+                for (int l = 0; l < L; l++)
+                    if (!lanes[l].st) { lanes[l].st = fresh[n_new++]; lanes[l].own_stream = true; }
+            }
+        }
         for (int l = 0; l < L; l++) {
             auto &ln = lanes[l];
-            if (!ln.st) { DOA_HIP_TRY(hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking)); ln.own_stream = true; }
             if (!detached && !ln.done) DOA_HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
             if (const int rc = prepare(ln); rc != DOA_OK) return rc;
         }

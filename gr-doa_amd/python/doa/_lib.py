@@ -138,6 +138,8 @@ SIGNATURES = {
     "doa_root_pipeline_inject_failure": (C.c_int, [_vp, C.c_int]),
     "doa_root_pipeline_lanes_idle": (C.c_int, [_vp]),
     "doa_hip_evd_fallback_counter_device_debug": (C.c_int, []),
+    "doa_hip_lane_streams_verified_debug": (C.c_int, []),
+    "doa_hip_lane_streams_set_aside_debug": (C.c_int, []),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

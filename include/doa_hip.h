@@ -36,6 +36,13 @@
  * created overlap kernels measurably worse than later ones (26 against 33 us per pipeline step); priming
  * the pool once makes every stream created afterwards -- the library's and the application's -- one of the good kind.
  * Set DOA_HIP_NO_QUEUE_PRIMING=1 in the environment to switch this off.
+ * The pipeline handles also PROBE the lane streams they create (first doa_*_pipeline_work_dev_batches / chunked host call on
+ * a handle): the runtime may put two streams on one hardware queue, where their kernels run one after the other (measured: a
+ * 4-lane step at 44 instead of 37.5 us with one foreign stream alive), and nothing in the HIP API tells; so every new lane
+ * and the lanes accepted before it run a one-wave kernel that sleeps 150 us and time-stamps itself, and a lane whose interval
+ * does not overlap the others' is replaced (csrc/lane_streams.hip).  About a millisecond per handle, once;
+ * DOA_HIP_NO_LANE_PROBE=1 switches it off.  Streams handed in with doa_*_pipeline_set_lane_streams are the caller's and
+ * are taken as they are.
  * Diagnostics, profiling and fault-injection entry points used by the test suite are exported by the same library but
  * declared in doa_hip_test.h, not here: this header is the drop-in boundary only.
  */

@@ -64,6 +64,13 @@ DOA_HIP_API int doa_root_pipeline_lanes_idle(doa_root_pipeline_t *h);
  * into another device's memory); the test creates a handle, binds its device and checks that this equals it. */
 DOA_HIP_API int doa_hip_evd_fallback_counter_device_debug(void);
 
+/* The lane streams of the pipeline handles are probed when they are created (gr-doa_amd/csrc/lane_streams.hip): how many
+ * lanes of the set created LAST in this process were seen to run their kernels side by side (-1: none created yet, or the
+ * probing is switched off with DOA_HIP_NO_LANE_PROBE), and how many candidate streams were set aside on the way because they
+ * shared a hardware queue with an accepted lane. */
+DOA_HIP_API int doa_hip_lane_streams_verified_debug(void);
+DOA_HIP_API int doa_hip_lane_streams_set_aside_debug(void);
+
 #ifdef __cplusplus
 }
 #endif
