@@ -634,9 +634,12 @@ def main():
                  (max(0, args.steps - n_streams), min(n_streams, args.steps), True)):
         prepare(*call)
     # setup, not warm-up: touch every lane / stream / buffer set once, so that first-launch code loading and lazy
-    # workspace allocation never fall into a short timed region whatever --warmup says
+    # workspace allocation never fall into a short timed region whatever --warmup says -- and the process group's first
+    # collectives (kernel loading, channel set-up) likewise: the barrier in front of the region is then a warm one
     run_steps(0, n_setup)
     torch.cuda.synchronize()
+    for _ in range(3):
+        barrier()
     if args.warmup > 0:
         run_steps(0, args.warmup)
     # Timed region: barrier + synchronize on both sides.  Each rank stops its clock when ITS K steps have completed
