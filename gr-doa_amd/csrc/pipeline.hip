@@ -325,8 +325,7 @@ int doa_music_pipeline_work(doa_music_pipeline_t *h, int noutput_items, const vo
     for (int k = 0; k < N; k++)
         if (!input_items[k]) { doa::set_error("music_pipeline_work: input_items[%d] is NULL", k); return DOA_ERR_INVALID_ARG; }
     if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
-    for (auto &st : h->hst)
-        if (!st) DOA_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (const int src = doa::ensure_stream_pair(h->hst); src != DOA_OK) return src;
     const size_t nonoverlap = (size_t)(h->K - h->ovl);
     // Scheduler-sized calls (a GNU Radio work() hands over a few to a few hundred items): the fixed costs are what
     // counts -- N pageable host-to-device copies, up to four copies back and two stream synchronisations.  Below

@@ -12,6 +12,16 @@ namespace doa {
 // n_new streams that were seen to run their kernels beside each other and beside the n_have given ones (lane_streams.hip)
 int create_lane_streams(const hipStream_t *have, int n_have, hipStream_t *out, int n_new);
 
+// the two copy / compute streams of the host-buffer entries, created on first use: the second is probed against the first
+inline int ensure_stream_pair(hipStream_t (&st)[2])
+{
+    for (int i = 0; i < 2; i++) {
+        if (st[i]) continue;
+        if (const int rc = create_lane_streams(&st[1 - i], st[1 - i] ? 1 : 0, &st[i], 1); rc != DOA_OK) return rc;
+    }
+    return DOA_OK;
+}
+
 struct PipeLane {
     hipStream_t st = nullptr;
     bool own_stream = true;         // false: adopted from the caller (doa_*_pipeline_set_lane_streams)

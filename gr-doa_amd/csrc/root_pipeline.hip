@@ -259,8 +259,7 @@ int doa_root_pipeline_work(doa_root_pipeline_t *h, int noutput_items, const void
     for (int k = 0; k < N; k++)
         if (!input_items[k]) { doa::set_error("root_pipeline_work: input_items[%d] is NULL", k); return DOA_ERR_INVALID_ARG; }
     if (int brc = doa::bind_device(h->device); brc != DOA_OK) return brc;
-    for (auto &st : h->hst)
-        if (!st) DOA_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (const int src = doa::ensure_stream_pair(h->hst); src != DOA_OK) return src;
     const size_t nonoverlap = (size_t)(h->K - h->ovl);
     const size_t n_all = (size_t)noutput_items;
     // result block on the device: [angles | status] per call, sections 256-byte aligned

@@ -104,7 +104,15 @@ def test_root_selection_rule_on_the_solvers_own_roots(N, M, d, thetas):
     assert blk.work(R.shape[0], [R], [out]) == R.shape[0] and np.array_equal(out, ang, equal_nan=True)
     assert not status.any()
     inside = (1.0 - np.abs(roots) > 0.0).sum(axis=1)
-    assert np.all(inside == N - 1), np.bincount(inside)            # conjugate-reciprocal pairs, none on the circle
+    assert np.all(inside[40:] == N - 1), np.bincount(inside[40:])  # full rank: conjugate-reciprocal pairs, none on the circle
+    # rank-deficient items have DOUBLE roots on the circle in exact arithmetic; rounding splits each pair either radially (one
+    # root inside, one outside: the usual case) or along the circle (two roots with |z| = 1 to the solver's accuracy, of which
+    # none need be strictly inside -- the reference's rule then reports 90 degrees for that source, :131-141, as checked below
+    # against the rule applied to these very roots).  Which of the two happens is decided within the ~1e-8 ball inside which a
+    # double root cannot be located in double precision (it changed with the solver's float phase in round 4).
+    on_circle = (np.abs(np.abs(roots[:40]) - 1.0) < 1e-8).sum(axis=1)
+    assert np.all(inside[:40] <= N - 1) and np.all(N - 1 - inside[:40] <= on_circle // 2), (inside[:40], on_circle)
+    assert (inside[:40] == N - 1).mean() >= 0.9                   # and the radial split stays the rule
     for i in range(R.shape[0]):
         want = oracle.root_music_select(roots[i], d, M, "f64")     # :122-145 on the device's roots
         assert np.array_equal(np.isnan(want), np.isnan(ang[i])), (i, want, ang[i])

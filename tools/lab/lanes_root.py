@@ -16,7 +16,10 @@ def streams(which):
         doa.sim_source(N, 0.4, [30.0, 123.0], [0.03125, 0.0625], None, None, 0.1, seed=600 + b).work_dev(span, [t.data_ptr() for t in s], st)
         out.append(s)
     return out
-for which in ("cfg3", "flow"):
+from doa._lib import lib
+WHICH = tuple(os.environ.get("LANES_WHICH", "cfg3,flow").split(","))
+LANES = tuple(int(x) for x in os.environ.get("LANES_LIST", "3,4,5,6,8").split(","))
+for which in WHICH:
     bufs = streams(which)
     ptrs = [[t.data_ptr() for t in s] for s in bufs]
     cov = [torch.empty((B, 16), dtype=torch.complex64, device="cuda") for _ in range(nbuf)]
@@ -25,7 +28,7 @@ for which in ("cfg3", "flow"):
     mx = [torch.empty((B, 2), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
     for steps in (20, 100):
         idx = [i % nbuf for i in range(steps)]
-        for lanes in (3, 4, 5, 6, 8):
+        for lanes in LANES:
             if which == "cfg3":
                 p = doa.root_pipeline(4, 1024, 0, 0, 0.44, 2, B); p.set_lanes(lanes)
                 call = p.prepare_batches(B, [ptrs[b] for b in idx], [cov[b].data_ptr() for b in idx], [ang[b].data_ptr() for b in idx], None, doa.DETACHED)
@@ -38,5 +41,5 @@ for which in ("cfg3", "flow"):
             for _ in range(5):
                 t0 = time.perf_counter(); call(); torch.cuda.synchronize()
                 best = min(best, (time.perf_counter() - t0) / steps * 1e6)
-            print(f"{which} steps {steps:3d} lanes {lanes}: {best:6.2f} us/step", flush=True)
+            print(f"{which} steps {steps:3d} lanes {lanes}: {best:6.2f} us/step   (lanes seen side by side: {lib.doa_hip_lane_streams_verified_debug()})", flush=True)
             del p
