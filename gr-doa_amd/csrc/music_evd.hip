@@ -613,10 +613,25 @@ __device__ __forceinline__ bool evd_quad_subspace(const float2 *__restrict__ Ri,
                     if (conv) {
                         if (cert) done = true;                  // X stays as it is from here on
                         else ok = false;                        // converged to SOME invariant subspace: the Jacobi decides
-                    } else if (!sane || En > 0.04 * bound * bound) {
-                        ok = false;                             // rate above 0.2 per step (or no bound at all): not worth iterating
+                    } else {
+                        // steps still to go, from above: the squared residual falls by at least bound^2 / En per step.  A step
+                        // costs this wave 0.8 us, the Jacobi it would run instead 9: more than kMoreSteps to go is not worth
+                        // iterating (the same comparison at every check; the old rule -- rate above 0.2 -- let quads run to the
+                        // 20-step limit AND take the Jacobi: 21.6 us per 4096 items at 5 dB SNR against the one-lane Jacobi's
+                        // 11.2, profiles/r04_lab_evd_quad_low_snr.txt)
+                        constexpr float kMoreSteps = 11.f;
+                        bool slow = !sane;
+                        if (sane) {
+                            const float need = __log2f((float)(res2 / ((3e-14 * 3e-14) * nrm2)));
+                            const float gain = __log2f((float)((bound * bound) / fmax(En, 1e-300)));
+                            slow = !(gain * kMoreSteps >= need);                 // (NaN: slow)
+                        }
+                        if (slow) ok = false;
                     }
                 }
+                // the Jacobi runs for the whole wave or not at all: once one quad needs it, iterating on in the others only adds
+                // to the wave's time
+                if (__builtin_amdgcn_ballot_w64(!ok) != 0ull && !done) ok = false;
             }
             next_check += (it < 8) ? 2 : (it == 8 ? 3 : (it == 11 ? 4 : 5));      // checks after 4, 6, 8, 11, 15, 20 steps
         }
@@ -1112,7 +1127,9 @@ static bool launch_evd_quad(int N, int M, int n_items, const void *d_R, void *d_
 {
     // two sources only: with three (N = 4: ONE noise eigenvalue) 1.6 % of random-direction items fall back and take their
     // waves with them -- 26 against the Jacobi's 11 us per 4096 items (profiles/r04_lab_evd_quad.txt)
-    if (N > 4 || M != 2 || M >= N) return false;
+    // and four antennas only: at N = 3 the one-lane Jacobi is the faster one by far (5.4 against 14.7 us per 4096 random-direction
+    // items: a 3 x 3 sweep is three rotations, and the quad spends a lane on padding; profiles/r04_lab_evd_noise_vector.txt)
+    if (N != 4 || M != 2) return false;
     const dim3 grid((n_items + 15) / 16), block(64);
 #define DOA_QUAD(M_, PN_)                                                                                                    \
     hipLaunchKernelGGL((music_evd_quad_kernel<M_, PN_>), grid, block, 0, st, (const float2 *)d_R, (float *)d_coef,              \

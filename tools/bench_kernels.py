@@ -19,6 +19,7 @@ ap.add_argument("--P", type=int, default=1024)
 ap.add_argument("--M", type=int, default=1)
 ap.add_argument("--ovl", type=int, default=0, help="overlap_size (windows advance by K-ovl samples)")
 ap.add_argument("--fb", type=int, default=0, help="avg_method (1 = forward-backward)")
+ap.add_argument("--snr", type=float, default=20.0, help="per-source SNR in dB of the random-direction data")
 ap.add_argument("--ablate", default="", help="mcov: multi-stream covariance only; mmusic: multi-stream MUSIC only")
 args = ap.parse_args()
 N, K, P, M, B = args.N, args.K, args.P, args.M, args.batch
@@ -42,7 +43,7 @@ for b in range(args.nbuf):
         doa.sim_source(N, 0.5, th, [0.03125, 0.0625, 0.11, 0.2][:M], None, None, 0.1, seed=600 + b).work_dev(span, [t.data_ptr() for t in s_], st)
         streams.append(s_)
     else:                                        # M sources at SNR 20 dB, a random direction set per snapshot
-        s_, _ = doa.sim.make_batch_streams_torch(N, K, B, 0.5, M, 20.0, seed=b)     # B*K >= (B-1)*STEP + K samples
+        s_, _ = doa.sim.make_batch_streams_torch(N, K, B, 0.5, M, args.snr, seed=b)     # B*K >= (B-1)*STEP + K samples
         streams.append(s_)
 PAD = int(os.environ.get("BENCH_CH_PAD", "-1"))        # >= 0: the N streams of a buffer set in one slab, PAD bytes between them
 if PAD >= 0:
