@@ -74,3 +74,54 @@ def test_more_lanes_than_hardware_queues_still_work():
             assert 4 <= lib.doa_hip_lane_streams_verified_debug() <= 8
         res.append(torch.stack(spec).cpu().numpy())
     assert np.array_equal(res[0].view(np.uint8), res[1].view(np.uint8))
+
+
+def test_handles_created_and_probed_from_several_threads_at_once():
+    """GNU Radio runs one thread per block: several fused handles may create and probe their lanes at the same time.  The probes
+    then disturb each other's timing (a probe kernel delayed by a neighbour's reads as 'not side by side' and costs a retry);
+    whatever they decide, every handle works and gives the single-lane results."""
+    import threading
+    n, steps, n_threads = 128, 8, 4
+    ins = [_flow_inputs(n, seed=60 + t) for t in range(n_threads)]
+    want = []
+    for t in range(n_threads):                       # single-lane references, one after the other
+        p = doa.music_pipeline(4, 2048, 512, 1, 0.4, 2, 1024, n)
+        p.set_lanes(1)
+        spec = [torch.empty((n, 1024), dtype=torch.float32, device="cuda") for _ in range(steps)]
+        mx = [torch.empty((n, 2), dtype=torch.float32, device="cuda") for _ in range(steps)]
+        am = [torch.empty((n, 2), dtype=torch.float32, device="cuda") for _ in range(steps)]
+        p.work_dev_batches(n, [[x.data_ptr() for x in ins[t]]] * steps, None, [x.data_ptr() for x in spec], [x.data_ptr() for x in mx],
+                           [x.data_ptr() for x in am], torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        want.append(torch.stack(spec).cpu().numpy())
+    got, err = [None] * n_threads, []
+    start = threading.Barrier(n_threads)
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(0)
+            p = doa.music_pipeline(4, 2048, 512, 1, 0.4, 2, 1024, n)
+            p.set_lanes(4)
+            spec = [torch.empty((n, 1024), dtype=torch.float32, device="cuda") for _ in range(steps)]
+            mx = [torch.empty((n, 2), dtype=torch.float32, device="cuda") for _ in range(steps)]
+            am = [torch.empty((n, 2), dtype=torch.float32, device="cuda") for _ in range(steps)]
+            call = p.prepare_batches(n, [[x.data_ptr() for x in ins[t]]] * steps, None, [x.data_ptr() for x in spec],
+                                     [x.data_ptr() for x in mx], [x.data_ptr() for x in am], doa.DETACHED)
+            start.wait()
+            call()                                   # creates and probes this handle's four lanes
+            p.synchronize()
+            call()
+            p.synchronize()
+            got[t] = torch.stack(spec).cpu().numpy()
+        except Exception as e:                       # pragma: no cover - reported by the main thread
+            err.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not err, err
+    for t in range(n_threads):
+        assert np.array_equal(got[t].view(np.uint8), want[t].view(np.uint8))
+    assert 1 <= lib.doa_hip_lane_streams_verified_debug() <= 4
